@@ -1,0 +1,177 @@
+/*
+ * mi_nerf.h -- C ABI of libmi_nerf.so: the MI355X (gfx950) NeRF volume-rendering hot path.
+ *
+ * The reference (nuggy875/NeRF_pytorch_paeng) has NO native/FFI layer: its hot path is the Python
+ * function surface of nerf_process.py / rays.py / model/ (SURVEY.md section 8(b)).  This header is the
+ * flat boundary a binding for that surface talks to: raw device pointers (tensor.data_ptr()), explicit
+ * sizes, scalars, a hipStream_t passed as void*, int status return (0 = ok).  No torch types, no
+ * exceptions, no hidden allocation: the caller allocates every output.  Error text: mi_nerf_last_error().
+ *
+ * Each entry point cites the reference code it replaces (file:line relative to the reference tree).
+ * All tensors are fp32, contiguous, row-major unless stated.  "dev" = device pointer, "host" = host pointer.
+ */
+#ifndef MI_NERF_H
+#define MI_NERF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_NERF_ABI_VERSION 1
+
+/* status codes */
+#define MI_NERF_OK 0
+#define MI_NERF_EINVAL 1   /* bad argument / unsupported shape */
+#define MI_NERF_EHIP 2     /* HIP runtime error (launch, etc.) */
+
+int mi_nerf_abi_version(void);
+/* Thread-local text of the last error on this thread ("" if none). */
+const char* mi_nerf_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Network description.  One NeRFModule: D trunk layers of width W, skip-concat of the encoded
+ * position after trunk layer `skip` (so trunk layer skip+1 takes [gamma(x), h]), density / feature /
+ * view-direction / colour heads (model/NeRF.py:10-52).  Supported by the kernels: W in {128, 256},
+ * 2 <= D <= 16, L_x = 10, L_d = 4, at most one skip (skip = -1: none; a skip index >= D-1 never fires,
+ * exactly like the reference's `range(D-1)` construction at model/NeRF.py:25).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct mi_nerf_net {
+    int32_t D;      /* trunk depth             (opts.netDepth, config.py:56) */
+    int32_t W;      /* trunk width             (opts.netWidth, config.py:57) */
+    int32_t skip;   /* skips=[4] -> 4; -1 none (model/NeRF.py:11,25,40)      */
+    int32_t L_x;    /* position frequencies    (config.py:54) -> 3+6*L_x input channels */
+    int32_t L_d;    /* direction frequencies   (config.py:55) */
+} mi_nerf_net;
+
+/* Host pointers to one NeRFModule's parameters in the reference checkpoint layout
+ * ([out,in] row-major weights; model/NeRF.py:24-30).  linear_x_w / linear_x_b are arrays of D pointers. */
+typedef struct mi_nerf_params {
+    const float* const* linear_x_w;   /* [D] : W x (in_x | W | W+in_x) */
+    const float* const* linear_x_b;   /* [D] : W                        */
+    const float* linear_density_w;    /* 1 x W     */
+    const float* linear_density_b;    /* 1         */
+    const float* linear_feat_w;       /* W x W     */
+    const float* linear_feat_b;       /* W         */
+    const float* linear_d_w;          /* W/2 x (W + in_d), input order [feature, gamma(d)] (NeRF.py:46) */
+    const float* linear_d_b;          /* W/2       */
+    const float* linear_color_w;      /* 3 x W/2   */
+    const float* linear_color_b;      /* 3         */
+} mi_nerf_params;
+
+/* Packed-weights blob: the kernels' streaming order (MFMA A-operand fragments in consumption order,
+ * then bias / head side tables).  Pack on the host, copy the blob to the device once, pass the device
+ * pointer to the mlp / render entry points.  Replaces nothing in the reference (state_dict ingest:
+ * train.py:105-114, test.py:20-21 load the same tensors). */
+size_t mi_nerf_packed_bytes(const mi_nerf_net* net);
+int mi_nerf_pack_weights(const mi_nerf_net* net, const mi_nerf_params* params, void* host_blob, size_t blob_bytes);
+/* dtype 1: bf16 stream for the bf16 MFMA variant (fp32 side tables). */
+size_t mi_nerf_packed_bytes_bf16(const mi_nerf_net* net);
+int mi_nerf_pack_weights_bf16(const mi_nerf_net* net, const mi_nerf_params* params, void* host_blob, size_t blob_bytes);
+
+/* ------------------------------------------------------------------------------------------------
+ * a1  make_o_d(img_w, img_h, img_k, pose)                                           rays.py:20-34
+ * Rays for image rows [row0, row0+n_rows) (whole image: 0, H).  k4 = {fx, fy, cx, cy} already rounded
+ * to fp32 (torch rounds the float64 K entries to fp32 when they meet the fp32 pixel grid); pose12 =
+ * row-major 3x4 camera-to-world.  Outputs [n_rows*W, 3] each; rays_o_dev may be NULL.
+ * ---------------------------------------------------------------------------------------------- */
+int mi_nerf_make_o_d(int W, int H, const float k4[4], const float pose12[12], int row0, int n_rows,
+                     float* rays_o_dev, float* rays_d_dev, void* stream);
+/* Same maths for an explicit list of flat pixel indices (int64, y*W+x): the 4096-ray benchmark batch. */
+int mi_nerf_make_o_d_pixels(int W, int H, const float k4[4], const float pose12[12], const int64_t* pix_dev,
+                            int64_t n, float* rays_o_dev, float* rays_d_dev, void* stream);
+
+/* a3  ndc_rays(H, W, focal, near, rays_o, rays_d)                          nerf_process.py:8-28
+ * o_in/d_in: [n,3] with arbitrary row strides in floats (stride 0 = broadcast origin, rays.py:33). */
+int mi_nerf_ndc_rays(int H, int W, float focal, float near_, const float* o_in_dev, int64_t o_stride,
+                     const float* d_in_dev, int64_t d_stride, int64_t n, float* o_out_dev, float* d_out_dev,
+                     void* stream);
+
+/* Counter-based U[0,1) generator: out[r, s] depends only on (seed, stream_id, ray0 + r, s), so any
+ * sharding/chunking of the rays sees the same numbers.  Stands in for torch.rand at
+ * nerf_process.py:58 (stream_id 0: t_rand) and :162 (stream_id 1: u). */
+int mi_nerf_fill_uniform(uint32_t seed, uint32_t stream_id, int64_t ray0, int64_t n_rays, int n_samples,
+                         float* out_dev, void* stream);
+
+/* a6  stratified coarse depths                                             nerf_process.py:42-60
+ * z[n, S] = lower + (upper - lower) * t_rand, bins linear in depth between near and far. */
+int mi_nerf_stratified_z(int64_t n_rays, int S, float near_, float far_, const float* t_rand_dev, float* z_dev,
+                         void* stream);
+
+/* a7  sample_pdf(bins, weights, N_samples, det)                          nerf_process.py:144-182
+ * bins [n, B], weights [n, B-1], u [n, N] (ignored / may be NULL when det != 0) -> samples [n, N]. */
+int mi_nerf_sample_pdf(const float* bins_dev, const float* weights_dev, int64_t n, int B, int N, int det,
+                       const float* u_dev, float* samples_dev, void* stream);
+/* a7  fine branch of pre_process                                          nerf_process.py:62-67
+ * z_c [n, Sc] (sorted), weights_c [n, Sc] -> z_fine [n, Sc+Nf] = sort(cat(z_c, sample_pdf(mid(z_c),
+ * weights_c[1:-1], Nf))); z_samples_dev (optional, [n, Nf]) receives the unsorted new samples. */
+int mi_nerf_fine_z(const float* z_c_dev, const float* weights_c_dev, int64_t n, int Sc, int Nf, int det,
+                   const float* u_dev, float* z_fine_dev, float* z_samples_dev, void* stream);
+
+/* a8  network input assembly                                    nerf_process.py:36-39,69-85
+ * rays [n,6] (o,d), z [n,S] -> embedded [n*S, (3+6L_x)+(3+6L_d)] = [gamma(o+d z), gamma(d/|d|)]
+ * (model/PositionalEncoding.py:7-36). */
+int mi_nerf_embed(const float* rays_dev, const float* z_dev, int64_t n_rays, int S, int L_x, int L_d,
+                  float* embedded_dev, void* stream);
+
+/* gamma(x): x [n,3] -> [n, 3+6L]  (the closure of get_positional_encoder, model/PositionalEncoding.py:33-36) */
+int mi_nerf_posenc(const float* x_dev, int64_t n, int L, float* out_dev, void* stream);
+
+/* a9  model(x)                                    model/NeRF.py:33-52,70-78; nerf_process.py:190-192
+ * x [n, in_x+in_d] pre-embedded rows -> out [n,4] = (rgb_raw, density_raw). */
+int mi_nerf_mlp_embedded(const mi_nerf_net* net, const void* packed_dev, const float* x_dev, int64_t n,
+                         float* out_dev, void* stream);
+/* a8+a9 fused: positional encoding computed in registers, no [n_pts, 90] tensor in HBM.
+ * rays [n,6], z [n,S] -> raw [n,S,4]. */
+int mi_nerf_mlp_rays(const mi_nerf_net* net, const void* packed_dev, const float* rays_dev, const float* z_dev,
+                     int64_t n_rays, int S, float* raw_dev, void* stream);
+/* bf16-MFMA variant of the fused entry (packed blob from mi_nerf_pack_weights_bf16). */
+int mi_nerf_mlp_rays_bf16(const mi_nerf_net* net, const void* packed_bf16_dev, const float* rays_dev,
+                          const float* z_dev, int64_t n_rays, int S, float* raw_dev, void* stream);
+
+/* a10 post_process(outputs, z_vals, rays_d)                              nerf_process.py:89-140
+ * raw [n,S,4], z [n,S], rays [n, ray_stride] with the direction at floats 3..5 when ray_stride == 6, or a
+ * bare [n,3] direction tensor when ray_stride == 3.  Any of acc/weights/depth may be NULL. */
+int mi_nerf_composite(const float* raw_dev, const float* z_dev, const float* rays_dev, int ray_stride, int64_t n,
+                      int S, float* rgb_dev, float* disp_dev, float* acc_dev, float* weights_dev,
+                      float* depth_dev, void* stream);
+
+/* a5  render_rays(rays, model, posenc, opts)                            nerf_process.py:185-216
+ * Whole coarse(+fine) pipeline for n rays on one stream, no host synchronisation.
+ * t_rand [n,Sc] and u [n,Nf] are always explicit (fill them with mi_nerf_fill_uniform or inject).
+ * Workspace (caller-allocated, mi_nerf_render_workspace_bytes): z_c, raw_c, weights_c, z_f, raw_f.
+ * Outputs: rgb_c [n,3], disp_c [n]; rgb_f [n,3], disp_f [n] when Nf > 0 (else may be NULL). */
+typedef struct mi_nerf_render_cfg {
+    float near_, far_;     /* opts.near / opts.far   (nerf_process.py:44,47) */
+    int32_t Sc, Nf;        /* opts.N_samples_c / _f  (config.py:72-73)       */
+    int32_t det;           /* opts.perturb == 0.     (nerf_process.py:65)    */
+    int32_t use_bf16;      /* 0: fp32 MFMA (default); 1: bf16 MFMA variant   */
+} mi_nerf_render_cfg;
+size_t mi_nerf_render_workspace_bytes(const mi_nerf_render_cfg* cfg, int64_t n_rays);
+int mi_nerf_render_rays(const mi_nerf_net* net, const void* packed_coarse_dev, const void* packed_fine_dev,
+                        const mi_nerf_render_cfg* cfg, const float* rays_dev, int64_t n_rays,
+                        const float* t_rand_dev, const float* u_dev, void* workspace_dev, size_t workspace_bytes,
+                        float* rgb_c_dev, float* disp_c_dev, float* rgb_f_dev, float* disp_f_dev, void* stream);
+/* Offsets (bytes) of the intermediates inside the workspace, for staged parity checks. */
+typedef struct mi_nerf_workspace_layout {
+    size_t z_c, raw_c, weights_c, z_f, raw_f, total;
+} mi_nerf_workspace_layout;
+int mi_nerf_render_workspace_layout(const mi_nerf_render_cfg* cfg, int64_t n_rays, mi_nerf_workspace_layout* out);
+
+/* Timing hook used by bench.py: average device time (ms) of `iters` back-to-back launches of the fused MLP
+ * kernel on `stream`, measured with hipEvents recorded on that same stream (torch.cuda.Event only sees
+ * torch's current stream).  Synchronises the stream. */
+int mi_nerf_time_mlp_rays(const mi_nerf_net* net, const void* packed_dev, const float* rays_dev, const float* z_dev,
+                          int64_t n_rays, int S, float* raw_dev, int iters, int use_bf16, float* avg_ms_out,
+                          void* stream);
+
+/* MFMA fragment-layout self test: runs a 32x32x(2k) product through the kernel's operand maps with
+ * asymmetric integer data and compares on the host.  Returns 0 when the maps hold. */
+int mi_nerf_selftest_mfma(void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI_NERF_H */

@@ -1,0 +1,69 @@
+"""Build libmi_nerf.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+    python -m nerf_pytorch_paeng_amd.build [--force]
+
+The shared library lands next to this file so that it travels with the repository snapshot to the
+GPU box (it is git-ignored, not gpurun-ignored).  Objects are cached under csrc/build/ keyed on
+source + header mtimes.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+LIB = os.path.join(HERE, "libmi_nerf.so")
+SOURCES = ["api.hip", "stages.hip", "mlp_fp32.hip", "mlp_bf16.hip", "pack.cpp"]
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: the MI355X path cannot be built (there is no CPU fallback)")
+    return exe
+
+
+def _deps_mtime() -> float:
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(INCLUDE, "mi_nerf.h")]
+    return max(os.path.getmtime(h) for h in hs)
+
+
+def _compile(src: str, force: bool) -> str:
+    bdir = os.path.join(CSRC, "build")
+    os.makedirs(bdir, exist_ok=True)
+    obj = os.path.join(bdir, src + ".o")
+    spath = os.path.join(CSRC, src)
+    if (not force and os.path.exists(obj) and os.path.getmtime(obj) >= os.path.getmtime(spath)
+            and os.path.getmtime(obj) >= _deps_mtime()):
+        return obj
+    cmd = [_hipcc(), *FLAGS, "-x", "hip", "-c", spath, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+    if r.stderr.strip():
+        sys.stderr.write(r.stderr)
+    return obj
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        objs = list(ex.map(lambda s: _compile(s, force), SOURCES))
+    if force or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
+        cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", LIB]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+        if verbose:
+            print(f"built {LIB} ({os.path.getsize(LIB) / 1024:.0f} KiB)")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_library(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,257 @@
+// api.hip -- extern "C" surface of libmi_nerf.so (include/mi_nerf.h): argument checks, error text,
+// the fused render_rays launch sequence, the hipEvent timing hook and the MFMA layout self test.
+#include <string>
+#include "common.h"
+#include "layout.h"
+
+namespace minerf {
+
+// ---- error plumbing --------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+int hip_fail(hipError_t e, const char* what) {
+    set_error("HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
+    return MI_NERF_EHIP;
+}
+
+// ---- implemented in the other translation units --------------------------------------------------
+int pack_fp32(const mi_nerf_net*, const mi_nerf_params*, void*, size_t);
+int pack_bf16(const mi_nerf_net*, const mi_nerf_params*, void*, size_t);
+size_t packed_bytes_bf16(const mi_nerf_net*);
+int mlp_rays_fp32(const mi_nerf_net*, const void*, const float*, const float*, int64_t, int, float*, hipStream_t);
+int mlp_embedded_fp32(const mi_nerf_net*, const void*, const float*, int64_t, float*, hipStream_t);
+int mlp_rays_bf16(const mi_nerf_net*, const void*, const float*, const float*, int64_t, int, float*, hipStream_t);
+int stage_make_o_d(int, int, const float*, const float*, int, int, float*, float*, hipStream_t);
+int stage_make_o_d_pixels(int, int, const float*, const float*, const int64_t*, int64_t, float*, float*, hipStream_t);
+int stage_ndc(int, int, float, float, const float*, int64_t, const float*, int64_t, int64_t, float*, float*, hipStream_t);
+int stage_fill_uniform(uint32_t, uint32_t, int64_t, int64_t, int, float*, hipStream_t);
+int stage_stratified(int64_t, int, float, float, const float*, float*, hipStream_t);
+int stage_embed(const float*, const float*, int64_t, int, int, int, float*, hipStream_t);
+int stage_posenc(const float*, int64_t, int, float*, hipStream_t);
+int stage_composite(const float*, const float*, const float*, int, int64_t, int, float*, float*, float*, float*, float*, hipStream_t);
+int stage_sample_pdf(const float*, const float*, int64_t, int, int, int, const float*, float*, hipStream_t);
+int stage_fine_z(const float*, const float*, int64_t, int, int, int, const float*, float*, float*, hipStream_t);
+
+static int check_net_basic(const mi_nerf_net* net) {
+    MN_CHECK_ARG(net != nullptr, "net is NULL");
+    MN_CHECK_ARG(net->W == 256 || net->W == 128, "unsupported width W=%d (kernels exist for 128 and 256)", net->W);
+    MN_CHECK_ARG(net->D >= 2 && net->D <= 16, "unsupported depth D=%d", net->D);
+    MN_CHECK_ARG(net->L_x == 10 && net->L_d == 4, "unsupported encoding L_x=%d L_d=%d (kernels exist for 10/4)", net->L_x, net->L_d);
+    MN_CHECK_ARG(net->skip >= -1, "bad skip=%d", net->skip);
+    return MI_NERF_OK;
+}
+
+static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+static int workspace_layout(const mi_nerf_render_cfg* cfg, int64_t n, mi_nerf_workspace_layout* L) {
+    MN_CHECK_ARG(cfg && L, "NULL cfg/layout");
+    MN_CHECK_ARG(n >= 0 && cfg->Sc >= 1 && cfg->Nf >= 0, "bad sizes n=%lld Sc=%d Nf=%d", (long long)n, cfg->Sc, cfg->Nf);
+    MN_CHECK_ARG(cfg->Nf == 0 || cfg->Sc >= 3, "hierarchical sampling needs at least 3 coarse samples");
+    size_t off = 0;
+    const size_t nn = (size_t)n, Sc = (size_t)cfg->Sc, St = (size_t)(cfg->Sc + cfg->Nf);
+    L->z_c = off;       off += align256(nn * Sc * 4);
+    L->raw_c = off;     off += align256(nn * Sc * 16);
+    L->weights_c = off; off += align256(nn * Sc * 4);
+    L->z_f = off;       off += cfg->Nf > 0 ? align256(nn * St * 4) : 0;
+    L->raw_f = off;     off += cfg->Nf > 0 ? align256(nn * St * 16) : 0;
+    L->total = off;
+    return MI_NERF_OK;
+}
+
+// ---- MFMA fragment-layout self test ------------------------------------------------------------
+// D[32][32] = A[32][8] * B[8][32] through four v_mfma_f32_32x32x2_f32, using exactly the operand and
+// result maps layout.h documents; integer-valued asymmetric data so any transposition shows up.
+__global__ void mfma_selftest_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ D) {
+    const int lane = threadIdx.x & 63;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int k = 2 * s + (lane >> 5);
+        const float a = A[(lane & 31) * 8 + k];     // A[i = lane&31][k]
+        const float b = B[k * 32 + (lane & 31)];    // B[k][j = lane&31]
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        D[i * 32 + (lane & 31)] = acc[r];
+    }
+}
+
+}  // namespace minerf
+
+using namespace minerf;
+
+extern "C" {
+
+int mi_nerf_abi_version(void) { return MI_NERF_ABI_VERSION; }
+const char* mi_nerf_last_error(void) { return g_err; }
+
+size_t mi_nerf_packed_bytes(const mi_nerf_net* net) {
+    if (check_net_basic(net)) return 0;
+    return make_layout(net->D, net->W, net->skip, net->L_x, net->L_d).total_bytes;
+}
+int mi_nerf_pack_weights(const mi_nerf_net* net, const mi_nerf_params* params, void* blob, size_t bytes) {
+    if (int rc = check_net_basic(net)) return rc;
+    MN_CHECK_ARG(params && blob, "NULL params/blob");
+    MN_CHECK_ARG(params->linear_x_w && params->linear_x_b && params->linear_density_w && params->linear_density_b &&
+                 params->linear_feat_w && params->linear_feat_b && params->linear_d_w && params->linear_d_b &&
+                 params->linear_color_w && params->linear_color_b, "NULL parameter pointer");
+    for (int l = 0; l < net->D; ++l) MN_CHECK_ARG(params->linear_x_w[l] && params->linear_x_b[l], "NULL trunk layer %d", l);
+    return pack_fp32(net, params, blob, bytes);
+}
+size_t mi_nerf_packed_bytes_bf16(const mi_nerf_net* net) {
+    if (check_net_basic(net)) return 0;
+    return packed_bytes_bf16(net);
+}
+int mi_nerf_pack_weights_bf16(const mi_nerf_net* net, const mi_nerf_params* params, void* blob, size_t bytes) {
+    if (int rc = check_net_basic(net)) return rc;
+    MN_CHECK_ARG(params && blob, "NULL params/blob");
+    return pack_bf16(net, params, blob, bytes);
+}
+
+int mi_nerf_make_o_d(int W, int H, const float k4[4], const float pose12[12], int row0, int n_rows, float* o, float* d, void* st) {
+    MN_CHECK_ARG(k4 && pose12, "NULL camera");
+    return stage_make_o_d(W, H, k4, pose12, row0, n_rows, o, d, (hipStream_t)st);
+}
+int mi_nerf_make_o_d_pixels(int W, int H, const float k4[4], const float pose12[12], const int64_t* pix, int64_t n, float* o,
+                            float* d, void* st) {
+    MN_CHECK_ARG(k4 && pose12, "NULL camera");
+    return stage_make_o_d_pixels(W, H, k4, pose12, pix, n, o, d, (hipStream_t)st);
+}
+int mi_nerf_ndc_rays(int H, int W, float focal, float near_, const float* o_in, int64_t os, const float* d_in, int64_t ds, int64_t n,
+                     float* o_out, float* d_out, void* st) {
+    return stage_ndc(H, W, focal, near_, o_in, os, d_in, ds, n, o_out, d_out, (hipStream_t)st);
+}
+int mi_nerf_fill_uniform(uint32_t seed, uint32_t stream_id, int64_t ray0, int64_t n_rays, int S, float* out, void* st) {
+    return stage_fill_uniform(seed, stream_id, ray0, n_rays, S, out, (hipStream_t)st);
+}
+int mi_nerf_stratified_z(int64_t n_rays, int S, float near_, float far_, const float* t_rand, float* z, void* st) {
+    return stage_stratified(n_rays, S, near_, far_, t_rand, z, (hipStream_t)st);
+}
+int mi_nerf_sample_pdf(const float* bins, const float* weights, int64_t n, int B, int N, int det, const float* u, float* out, void* st) {
+    return stage_sample_pdf(bins, weights, n, B, N, det, u, out, (hipStream_t)st);
+}
+int mi_nerf_fine_z(const float* z_c, const float* w_c, int64_t n, int Sc, int Nf, int det, const float* u, float* z_f, float* z_s,
+                   void* st) {
+    return stage_fine_z(z_c, w_c, n, Sc, Nf, det, u, z_f, z_s, (hipStream_t)st);
+}
+int mi_nerf_embed(const float* rays, const float* z, int64_t n_rays, int S, int L_x, int L_d, float* out, void* st) {
+    return stage_embed(rays, z, n_rays, S, L_x, L_d, out, (hipStream_t)st);
+}
+int mi_nerf_posenc(const float* x, int64_t n, int L, float* out, void* st) { return stage_posenc(x, n, L, out, (hipStream_t)st); }
+int mi_nerf_mlp_embedded(const mi_nerf_net* net, const void* packed, const float* x, int64_t n, float* out, void* st) {
+    return mlp_embedded_fp32(net, packed, x, n, out, (hipStream_t)st);
+}
+int mi_nerf_mlp_rays(const mi_nerf_net* net, const void* packed, const float* rays, const float* z, int64_t n_rays, int S, float* raw,
+                     void* st) {
+    return mlp_rays_fp32(net, packed, rays, z, n_rays, S, raw, (hipStream_t)st);
+}
+int mi_nerf_mlp_rays_bf16(const mi_nerf_net* net, const void* packed, const float* rays, const float* z, int64_t n_rays, int S,
+                          float* raw, void* st) {
+    return mlp_rays_bf16(net, packed, rays, z, n_rays, S, raw, (hipStream_t)st);
+}
+int mi_nerf_composite(const float* raw, const float* z, const float* rays, int ray_stride, int64_t n, int S, float* rgb, float* disp,
+                      float* acc, float* weights, float* depth, void* st) {
+    return stage_composite(raw, z, rays, ray_stride, n, S, rgb, disp, acc, weights, depth, (hipStream_t)st);
+}
+
+size_t mi_nerf_render_workspace_bytes(const mi_nerf_render_cfg* cfg, int64_t n_rays) {
+    mi_nerf_workspace_layout L;
+    if (workspace_layout(cfg, n_rays, &L)) return 0;
+    return L.total;
+}
+int mi_nerf_render_workspace_layout(const mi_nerf_render_cfg* cfg, int64_t n_rays, mi_nerf_workspace_layout* out) {
+    return workspace_layout(cfg, n_rays, out);
+}
+
+int mi_nerf_render_rays(const mi_nerf_net* net, const void* packed_c, const void* packed_f, const mi_nerf_render_cfg* cfg,
+                        const float* rays, int64_t n, const float* t_rand, const float* u, void* ws, size_t ws_bytes,
+                        float* rgb_c, float* disp_c, float* rgb_f, float* disp_f, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    mi_nerf_workspace_layout L;
+    if (int rc = workspace_layout(cfg, n, &L)) return rc;
+    MN_CHECK_ARG(ws_bytes >= L.total, "workspace too small: %zu < %zu", ws_bytes, L.total);
+    MN_CHECK_ARG(rays && t_rand && rgb_c && disp_c && packed_c && (ws || L.total == 0), "NULL pointer");
+    MN_CHECK_ARG(cfg->Nf == 0 || (packed_f && rgb_f && disp_f && (cfg->det || u)), "fine pass needs packed_fine, outputs and u");
+    if (n == 0) return MI_NERF_OK;
+    char* w = (char*)ws;
+    float* z_c = (float*)(w + L.z_c);
+    float* raw_c = (float*)(w + L.raw_c);
+    float* wts_c = (float*)(w + L.weights_c);
+    const int Sc = cfg->Sc, St = cfg->Sc + cfg->Nf;
+    // 1-a) stratified depths; 2-a) coarse net; 3-a) composite          (nerf_process.py:187-198)
+    if (int rc = stage_stratified(n, Sc, cfg->near_, cfg->far_, t_rand, z_c, st)) return rc;
+    if (int rc = cfg->use_bf16 ? mlp_rays_bf16(net, packed_c, rays, z_c, n, Sc, raw_c, st)
+                               : mlp_rays_fp32(net, packed_c, rays, z_c, n, Sc, raw_c, st)) return rc;
+    if (int rc = stage_composite(raw_c, z_c, rays, 6, n, Sc, rgb_c, disp_c, nullptr, wts_c, nullptr, st)) return rc;
+    if (cfg->Nf > 0) {
+        // 1-b) resample + merge; 2-b) fine net over all Sc+Nf depths; 3-b) composite   (:200-213)
+        float* z_f = (float*)(w + L.z_f);
+        float* raw_f = (float*)(w + L.raw_f);
+        if (int rc = stage_fine_z(z_c, wts_c, n, Sc, cfg->Nf, cfg->det, u, z_f, nullptr, st)) return rc;
+        if (int rc = cfg->use_bf16 ? mlp_rays_bf16(net, packed_f, rays, z_f, n, St, raw_f, st)
+                                   : mlp_rays_fp32(net, packed_f, rays, z_f, n, St, raw_f, st)) return rc;
+        if (int rc = stage_composite(raw_f, z_f, rays, 6, n, St, rgb_f, disp_f, nullptr, nullptr, nullptr, st)) return rc;
+    }
+    return MI_NERF_OK;
+}
+
+int mi_nerf_time_mlp_rays(const mi_nerf_net* net, const void* packed, const float* rays, const float* z, int64_t n_rays, int S,
+                          float* raw, int iters, int use_bf16, float* avg_ms, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    MN_CHECK_ARG(iters >= 1 && avg_ms, "bad iters / NULL output");
+    hipEvent_t e0, e1;
+    MN_HIP(hipEventCreate(&e0));
+    MN_HIP(hipEventCreate(&e1));
+    int rc = MI_NERF_OK;
+    MN_HIP(hipEventRecord(e0, st));
+    for (int i = 0; i < iters && rc == MI_NERF_OK; ++i)
+        rc = use_bf16 ? mlp_rays_bf16(net, packed, rays, z, n_rays, S, raw, st) : mlp_rays_fp32(net, packed, rays, z, n_rays, S, raw, st);
+    MN_HIP(hipEventRecord(e1, st));
+    MN_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    MN_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *avg_ms = ms / (float)iters;
+    return rc;
+}
+
+int mi_nerf_selftest_mfma(void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    float hA[32 * 8], hB[8 * 32], hD[32 * 32], ref[32 * 32];
+    for (int i = 0; i < 32; ++i) for (int k = 0; k < 8; ++k) hA[i * 8 + k] = (float)((i * 3 + k * 7) % 11 - 5);
+    for (int k = 0; k < 8; ++k) for (int j = 0; j < 32; ++j) hB[k * 32 + j] = (float)((k * 5 + j * 2 + (j > 9)) % 13 - 6);
+    for (int i = 0; i < 32; ++i) for (int j = 0; j < 32; ++j) {
+        float s = 0.f;
+        for (int k = 0; k < 8; ++k) s += hA[i * 8 + k] * hB[k * 32 + j];
+        ref[i * 32 + j] = s;
+    }
+    float *dA, *dB, *dD;
+    MN_HIP(hipMalloc(&dA, sizeof(hA)));
+    MN_HIP(hipMalloc(&dB, sizeof(hB)));
+    MN_HIP(hipMalloc(&dD, sizeof(hD)));
+    MN_HIP(hipMemcpyAsync(dA, hA, sizeof(hA), hipMemcpyHostToDevice, st));
+    MN_HIP(hipMemcpyAsync(dB, hB, sizeof(hB), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(mfma_selftest_kernel, dim3(1), dim3(64), 0, st, dA, dB, dD);
+    MN_LAUNCH_CHECK("mfma_selftest_kernel");
+    MN_HIP(hipMemcpyAsync(hD, dD, sizeof(hD), hipMemcpyDeviceToHost, st));
+    MN_HIP(hipStreamSynchronize(st));
+    (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dD);
+    for (int i = 0; i < 32 * 32; ++i)
+        if (hD[i] != ref[i]) {
+            set_error("MFMA layout mismatch at D[%d][%d]: got %g want %g", i / 32, i % 32, hD[i], ref[i]);
+            return MI_NERF_EINVAL;
+        }
+    return MI_NERF_OK;
+}
+
+}  // extern "C"

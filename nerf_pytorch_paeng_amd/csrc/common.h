@@ -1,0 +1,77 @@
+// common.h -- error plumbing and small device helpers shared by all translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include "../../include/mi_nerf.h"
+
+namespace minerf {
+
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what);
+
+#define MN_CHECK_ARG(cond, ...)                  \
+    do {                                         \
+        if (!(cond)) {                           \
+            ::minerf::set_error(__VA_ARGS__);    \
+            return MI_NERF_EINVAL;               \
+        }                                        \
+    } while (0)
+
+#define MN_HIP(call)                                                   \
+    do {                                                               \
+        hipError_t e__ = (call);                                       \
+        if (e__ != hipSuccess) return ::minerf::hip_fail(e__, #call);  \
+    } while (0)
+
+#define MN_LAUNCH_CHECK(name)                                                \
+    do {                                                                     \
+        hipError_t e__ = hipGetLastError();                                  \
+        if (e__ != hipSuccess) return ::minerf::hip_fail(e__, "launch " name); \
+    } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------------------
+// counter-based uniform generator (numpy mirror: oracle/restate.py counter_uniform)
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ inline uint32_t fmix32(uint32_t h) {
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+__host__ __device__ inline float counter_uniform(uint32_t seed, uint32_t stream_id, uint32_t ray, uint32_t sample) {
+    uint32_t h = fmix32(ray + 0x9E3779B9u * seed + 0x632BE5ABu);
+    h = fmix32(h ^ (sample * 0x85EBCA6Bu + stream_id * 0xC2B2AE35u + 0x27D4EB2Fu));
+    return (float)(h >> 8) * (1.0f / 16777216.0f);
+}
+
+// ---------------------------------------------------------------------------------------------
+// accurate sin / cos for positional encoding.  Arguments are 2^k * x (exact in fp32) and reach
+// ~3e3 rad for lego, so the reduction matters: 3-term Cody-Waite with FMA (pi/2 = HI + MID + LO),
+// then the Cephes single-precision minimax polynomials on [-pi/4, pi/4].  |error| <~ 1.5e-7.
+// quad_shift 0 -> sin(y), 1 -> cos(y) (cos y = sin(y + pi/2): same reduction, next quadrant).
+// Beyond 2^22 the float multiple count is no longer exact: fall back to the libm path.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sin_cos_fast(float y, int quad_shift) {
+    const float nf = __builtin_rintf(y * 0.636619772367581343f);
+    float r = __builtin_fmaf(-nf, 1.57079637050628662109375f, y);
+    r = __builtin_fmaf(-nf, -4.371138828673793e-08f, r);
+    r = __builtin_fmaf(-nf, -1.7151245100058819e-15f, r);
+    const int q = (int)nf + quad_shift;
+    const float r2 = r * r;
+    float sp = __builtin_fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
+    sp = __builtin_fmaf(sp, r2, -1.6666654611e-1f);
+    sp = __builtin_fmaf(sp * r2, r, r);
+    float cp = __builtin_fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    cp = __builtin_fmaf(cp, r2, 4.166664568298827e-2f);
+    cp = __builtin_fmaf(cp * r2, r2, __builtin_fmaf(-0.5f, r2, 1.0f));
+    const float v = (q & 1) ? cp : sp;
+    return (q & 2) ? -v : v;
+}
+// |y| below this bound keeps the float multiple count exact; callers branch ONCE per point on the largest
+// argument and use the libm path (sinf/cosf, Payne-Hanek) for anything bigger or non-finite.
+constexpr float SINCOS_FAST_LIMIT = 4.0e6f;
+__device__ __forceinline__ float sin_cos_slow(float y, int quad_shift) { return quad_shift ? cosf(y) : sinf(y); }
+
+}  // namespace minerf

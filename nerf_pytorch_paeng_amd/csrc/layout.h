@@ -1,0 +1,86 @@
+// layout.h -- packed-weight blob layout shared by the host packer (pack.cpp) and the kernels.
+//
+// The MLP kernels keep a 32-point tile's activations in registers in MFMA accumulator layout and feed
+// the accumulator of layer l straight back as the B operand of layer l+1.  That fixes, per k-step, WHICH
+// input feature each half of the wave contributes, so the weights (the A operand) are stored pre-permuted
+// in exactly the order the kernel consumes them ("stream"), as 1 KiB "quads":
+//
+//   quad(T, kq) = A fragments of output tile T (32 output features) for k-steps 4kq..4kq+3:
+//                 float [64 lanes][4]  -> one ds_read_b128 per lane yields 4 MFMA A operands.
+//   lane l: i = l & 31 (output feature 32T+i), hh = l >> 5 (which of the k-step's two input features)
+//
+// v_mfma_f32_32x32x2_f32: A[i][k] lane l -> i=l&31,k=l>>5;  B[k][j] lane l -> k=l>>5,j=l&31;
+// D[i][j]: j = l&31, i = (reg&3) + 8*(reg>>2) + 4*(l>>5).
+// Hence accumulator register r of output tile t, on lane half hh, holds feature
+//   feat(t, r, hh) = 32t + (r&3) + 8*(r>>2) + 4*hh        (for point j = l&31)
+// and k-step s = 16t + r of the next layer multiplies features (feat(t,r,0), feat(t,r,1)).
+//
+// Encoded inputs (gamma(x), gamma(d)) are produced per lane as: k-step s < 3L -> level k=s/3, axis c=s%3,
+// half 0 = sin(2^k p_c) (channel 3+6k+c), half 1 = cos(2^k p_c) (channel 3+6k+3+c);
+// s = 3L -> (p_x, p_y); s = 3L+1 -> (p_z, zero pad); rest zero pad to a multiple of 4 k-steps.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+
+namespace minerf {
+
+constexpr int QUAD_BYTES = 1024;
+constexpr int SLOT_QUADS = 16;
+constexpr int SLOT_BYTES = QUAD_BYTES * SLOT_QUADS;   // 16 KiB ring slot
+constexpr int HEADER_BYTES = 1024;
+constexpr uint32_t BLOB_MAGIC = 0x4D494E46u;          // 'MINF'
+
+__host__ __device__ constexpr int pe_ksteps(int L) { return ((3 * L + 2 + 3) / 4) * 4; }   // padded to 4
+
+struct BlobLayout {
+    // all byte offsets from the blob start
+    uint32_t stream_off;          // == HEADER_BYTES
+    uint32_t stream_bytes_hoist;  // stream length when the view-direction part of linear_d is hoisted (fused mode)
+    uint32_t stream_bytes_full;   // ... including the per-point direction k-steps (embedded mode)
+    uint32_t side_off;            // fp32 side tables, natural feature order
+    uint32_t side_floats;         // padded to a multiple of 4
+    // side-table sub-offsets, in floats from side start
+    uint32_t bias_trunk;          // D x W
+    uint32_t bias_feat;           // W
+    uint32_t bias_d;              // W/2
+    uint32_t dens_w;              // W
+    uint32_t dens_b;              // 1 (+3 pad)
+    uint32_t color_w;             // 3 x W/2
+    uint32_t color_b;             // 3 (+1 pad)
+    uint32_t wdir_t;              // in_d x W/2  (transposed direction block of linear_d)
+    uint32_t total_bytes;
+};
+
+__host__ __device__ inline uint32_t round_up_u32(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
+
+// elem_bytes: 4 (fp32 stream) or 2 (bf16 stream; quads keep 1 KiB, see mlp_bf16.hip)
+inline BlobLayout make_layout(int D, int W, int skip, int L_x, int L_d) {
+    BlobLayout b{};
+    const int NT = W / 32;
+    const int in_d = 3 + 6 * L_d;
+    const uint32_t pe_quads = (uint32_t)(pe_ksteps(L_x) / 4) * NT;
+    const uint32_t h_quads = (uint32_t)(W / 2 / 4) * NT;
+    uint32_t quads = pe_quads;                                     // trunk layer 0
+    for (int l = 1; l < D; ++l) quads += h_quads + ((skip >= 0 && l == skip + 1) ? pe_quads : 0);
+    quads += h_quads;                                              // linear_feat
+    quads += (uint32_t)(W / 2 / 4) * (NT / 2);                     // linear_d, feature part
+    b.stream_off = HEADER_BYTES;
+    b.stream_bytes_hoist = round_up_u32(quads, SLOT_QUADS) * QUAD_BYTES;
+    uint32_t full = round_up_u32(quads, SLOT_QUADS) + round_up_u32((uint32_t)(pe_ksteps(L_d) / 4) * (NT / 2), SLOT_QUADS);
+    b.stream_bytes_full = full * QUAD_BYTES;
+    b.side_off = b.stream_off + b.stream_bytes_full;
+    uint32_t f = 0;
+    b.bias_trunk = f; f += (uint32_t)D * W;
+    b.bias_feat = f;  f += W;
+    b.bias_d = f;     f += W / 2;
+    b.dens_w = f;     f += W;
+    b.dens_b = f;     f += 4;
+    b.color_w = f;    f += 3 * (W / 2);
+    b.color_b = f;    f += 4;
+    b.wdir_t = f;     f += (uint32_t)in_d * (W / 2);
+    b.side_floats = round_up_u32(f, 4);
+    b.total_bytes = b.side_off + b.side_floats * 4;
+    return b;
+}
+
+}  // namespace minerf

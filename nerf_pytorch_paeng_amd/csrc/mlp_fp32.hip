@@ -1,0 +1,422 @@
+// mlp_fp32.hip -- fused positional-encoding + NeRF MLP forward on fp32 MFMA (gfx950).
+//
+// Replaces: nerf_process.py:69-85 (point build + posenc), :190-194 / :206-209 (chunked model eval),
+//           model/NeRF.py:33-52 (NeRFModule.forward), model/PositionalEncoding.py:29-30.
+//
+// Design (MI355X-first):
+//   * one persistent 256-thread workgroup per CU, ONE wave per SIMD with the whole 512-entry register file;
+//   * a wave owns 32 points (MFMA column j = lane & 31) and keeps all their activations in registers in
+//     v_mfma_f32_32x32x2_f32 accumulator layout; the accumulator of layer l IS the B operand of layer l+1
+//     (bias + ReLU applied in place) -- activations never touch LDS or HBM;
+//   * weights are the A operand, pre-permuted on the host into consumption order ("stream" of 1 KiB quads,
+//     layout.h) and streamed L2 -> LDS by LDS-DMA (global_load_lds_dwordx4) into a 4-slot x 16 KiB ring
+//     shared by the 4 waves; one barrier per slot = per 64 MFMAs per wave;
+//   * gamma(x) is computed in registers per lane (sin on lanes 0-31, cos on lanes 32-63 of each k-step);
+//     in fused mode the view-direction block of linear_d is hoisted to a per-ray bias (it is constant
+//     over a ray's samples), density and colour heads run on the VALU as register dot products.
+#include "common.h"
+#include "layout.h"
+
+namespace minerf {
+
+constexpr int NSLOT = 4;
+constexpr int RING_BYTES = NSLOT * SLOT_BYTES;
+
+struct MlpArgs {
+    const char* stream;       // device: blob + stream_off
+    const float* side;        // device: blob + side_off
+    const float* rays;        // MODE 0: [n_rays, 6]
+    const float* z;           // MODE 0: [n_rays, S]
+    const float* x;           // MODE 1: [n_pts, in_x + in_d]
+    float* out;               // [n_pts, 4]
+    long long n_wtiles;       // 32-point wave tiles
+    long long n_pts;          // MODE 1
+    int S;                    // MODE 0
+    int tpr;                  // MODE 0: wave tiles per ray = ceil(S / 32)
+    int D;
+    int skip_layer;           // trunk layer index that consumes [gamma(x), h]; -1: none
+    unsigned stream_bytes;    // hoisted or full length, multiple of SLOT_BYTES
+    unsigned side_floats;
+    unsigned o_bias_trunk, o_bias_feat, o_bias_d, o_dens_w, o_dens_b, o_color_w, o_color_b, o_wdir_t;
+};
+
+// ---------------------------------------------------------------------------------------------
+// weight ring: NSLOT x 16 KiB in LDS, filled by LDS-DMA three slots ahead of the consumer.
+//
+// The DMA is issued from inline asm so that hipcc neither counts it (a counted DMA makes every
+// __syncthreads() drain vmcnt(0), i.e. wait for the prefetch just issued) nor moves it; we count it
+// ourselves: each ring_advance issues exactly 4 global_load_lds_dwordx4 per wave and waits vmcnt(4)
+// before the barrier, i.e. for everything except the 4 issued at the previous advance.
+//   advance to slot p: [vmcnt(4)] -> slots <= p+1 of this wave's share have landed; barrier -> of every
+//   wave's share, and every wave has completed its LDS reads of slot p-1 (lgkmcnt(0) is part of the
+//   barrier); then fetch slot p+3 into ring[(p+3)&3] == ring[(p-1)&3].
+// Compiler-counted loads/stores elsewhere in the kernel only ever over-wait because of the uncounted DMA
+// (vmcnt retires in order), never under-wait.
+// ---------------------------------------------------------------------------------------------
+struct WRing {
+    const char* gsrc;       // per-lane global pointer: stream + wave*4 KiB + lane*16
+    unsigned fetch_off;     // stream byte offset of the next slot to fetch
+    unsigned stream_bytes;
+    unsigned fetch_lds;     // LDS byte address (wave-uniform) this wave's share of the next fetch lands at
+    unsigned lds_lo, lds_hi;  // this wave's share of ring slot 0 / one past the last slot
+    unsigned read_slot;     // ring slot being consumed
+};
+
+__device__ __forceinline__ void dma16(const char* gptr, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gptr), "s"(lds_addr)
+        : "memory");
+}
+
+__device__ __forceinline__ void dma_slot(WRing& r) {
+    const char* g = r.gsrc + r.fetch_off;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma16(g + i * QUAD_BYTES, r.fetch_lds + i * QUAD_BYTES);
+    r.fetch_off += SLOT_BYTES;
+    if (r.fetch_off >= r.stream_bytes) r.fetch_off = 0;
+    r.fetch_lds += SLOT_BYTES;
+    if (r.fetch_lds >= r.lds_hi) r.fetch_lds = r.lds_lo;
+}
+
+__device__ __forceinline__ void ring_advance(WRing& r) {
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __syncthreads();
+    dma_slot(r);
+    r.read_slot = (r.read_slot + 1) & (NSLOT - 1);
+}
+
+__device__ __forceinline__ f32x4 ring_read(const char* smem, const WRing& r, int lane, int quad_in_slot) {
+    return *(const f32x4*)(smem + r.read_slot * SLOT_BYTES + lane * 16 + quad_in_slot * QUAD_BYTES);
+}
+
+// ---------------------------------------------------------------------------------------------
+// one GEMM part: acc[0..NT) += A(stream) x B, B = KS per-lane registers b[0..KS).
+// `a` is the A-operand pipeline: on entry it holds this part's quads (kq=0, t<NT), already read from
+// LDS; after the 4 MFMAs that consume a[t] the quad NT positions further down the stream is read into
+// it, so every LDS read has a full k-quad (NT*4 MFMAs) of lead time.  On exit `a` holds the first
+// NT_NEXT quads of the NEXT part (parts are slot aligned, the stream is consumed strictly in order).
+// MFMA order is t-major: 4 back-to-back dependent MFMAs per tile (dependent issue = 64 cycles = the
+// issue interval of v_mfma_f32_32x32x2_f32, so the chain costs nothing).
+// ---------------------------------------------------------------------------------------------
+template <int NT, int KS, int NT_NEXT, int NB>
+__device__ __forceinline__ void gemm_part(f32x16 (&acc)[8], const float (&b)[NB], f32x4 (&a)[8], const char* smem,
+                                          WRing& ring, int lane) {
+    static_assert(KS % 4 == 0 && KS <= NB, "k-steps come in quads");
+    constexpr int KQ = KS / 4;
+#pragma unroll
+    for (int kq = 0; kq < KQ; ++kq) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][j], b[4 * kq + j], acc[t], 0, 0, 0);
+            if (kq + 1 < KQ) {
+                const int q = (kq + 1) * NT + t;                       // quad index inside this part
+                if (q % SLOT_QUADS == 0) ring_advance(ring);
+                a[t] = ring_read(smem, ring, lane, q % SLOT_QUADS);
+            } else if (t < NT_NEXT) {
+                if (t == 0) ring_advance(ring);                        // next part starts a fresh slot
+                a[t] = ring_read(smem, ring, lane, t);
+            }
+            // pin the (4 MFMA, 1 LDS read) group order: left alone, hipcc sinks each read to just before
+            // its first use and exposes the LDS latency on every tile
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#pragma unroll
+    for (int t = NT; t < NT_NEXT; ++t) a[t] = ring_read(smem, ring, lane, t);
+}
+
+// acc tile t <- 32 floats of a natural-order vector in LDS (bias): register r of lane half hh holds
+// feature 32t + (r&3) + 8*(r>>2) + 4*hh  -> four 16-byte reads at 32t + 8g + 4hh.
+template <int NT>
+__device__ __forceinline__ void acc_init(f32x16 (&acc)[8], const float* vec_lds, int hh) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 v = *(const f32x4*)(vec_lds + 32 * t + 8 * g + 4 * hh);
+            acc[t][4 * g + 0] = v[0]; acc[t][4 * g + 1] = v[1]; acc[t][4 * g + 2] = v[2]; acc[t][4 * g + 3] = v[3];
+        }
+}
+
+template <int NT, bool RELU, int NB>
+__device__ __forceinline__ void acc_to_b(const f32x16 (&acc)[8], float (&h)[NB]) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h[16 * t + r] = RELU ? __builtin_fmaxf(acc[t][r], 0.0f) : acc[t][r];
+}
+
+// sum_i h[i] * w[feat(i, hh)] over this lane's half; w natural order in LDS
+template <int N, int NB>
+__device__ __forceinline__ float dot_half(const float (&h)[NB], const float* w_lds, int hh) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+    for (int q = 0; q < N / 4; ++q) {        // q = 4t + g : features 32t + 8g + 4hh + {0..3}
+        const f32x4 w = *(const f32x4*)(w_lds + 8 * q + 4 * hh);
+        s0 = __builtin_fmaf(h[4 * q + 0], w[0], s0);
+        s1 = __builtin_fmaf(h[4 * q + 1], w[1], s1);
+        s2 = __builtin_fmaf(h[4 * q + 2], w[2], s2);
+        s3 = __builtin_fmaf(h[4 * q + 3], w[3], s3);
+    }
+    return (s0 + s1) + (s2 + s3);
+}
+
+__device__ __forceinline__ float xhalf_sum(float v) { return v + __shfl_xor(v, 32, 64); }
+
+// encoded-input registers for k-step s: level k = s/3, axis c = s%3
+template <int L, bool SLOW, int NPE>
+__device__ __forceinline__ void encode_regs(float (&pe)[NPE], const float (&p)[3], int hh) {
+#pragma unroll
+    for (int s = 0; s < 3 * L; ++s) {
+        const float y = p[s % 3] * (float)(1 << (s / 3));      // exact: power-of-two scale
+        pe[s] = SLOW ? sin_cos_slow(y, hh) : sin_cos_fast(y, hh);
+    }
+    pe[3 * L] = hh ? p[1] : p[0];
+    pe[3 * L + 1] = hh ? 0.0f : p[2];
+#pragma unroll
+    for (int s = 3 * L + 2; s < NPE; ++s) pe[s] = 0.0f;
+}
+
+// gather the same registers from a pre-embedded row (MODE 1)
+template <int L, int NPE>
+__device__ __forceinline__ void gather_regs(float (&pe)[NPE], const float* row, int hh, bool valid) {
+#pragma unroll
+    for (int s = 0; s < 3 * L; ++s) {
+        const int ch = 3 + 6 * (s / 3) + (s % 3) + 3 * hh;
+        pe[s] = valid ? row[ch] : 0.0f;
+    }
+    pe[3 * L] = valid ? row[hh] : 0.0f;
+    pe[3 * L + 1] = (valid && !hh) ? row[2] : 0.0f;
+#pragma unroll
+    for (int s = 3 * L + 2; s < NPE; ++s) pe[s] = 0.0f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// the kernel.  MODE 0: rays + z (fused posenc, hoisted view-direction bias).  MODE 1: embedded rows.
+// ---------------------------------------------------------------------------------------------
+template <int W, int MODE, int LX, int LD>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void mlp_fp32_kernel(const MlpArgs a) {
+    constexpr int NT = W / 32;          // output tiles of a W-wide layer
+    constexpr int HN = W / 2;           // activation registers per lane
+    constexpr int KPE = pe_ksteps(LX);  // 32
+    constexpr int KDE = pe_ksteps(LD);  // 16
+    constexpr int IN_X = 3 + 6 * LX, IN_D = 3 + 6 * LD;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* side = (float*)(smem + RING_BYTES);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 31, hh = lane >> 5;
+    float* scratch = side + a.side_floats + wave * (W / 2);   // per-wave hoisted direction bias
+
+    for (unsigned i = tid * 4; i < a.side_floats; i += 256 * 4) *(f32x4*)(side + i) = *(const f32x4*)(a.side + i);
+
+    const long long n_wg_tiles = (a.n_wtiles + 3) >> 2;
+    if ((long long)blockIdx.x >= n_wg_tiles) return;     // host never launches such a block
+
+    WRing ring;
+    ring.gsrc = a.stream + wave * (4 * QUAD_BYTES) + lane * 16;
+    ring.fetch_off = 0;
+    ring.stream_bytes = a.stream_bytes;
+    ring.lds_lo = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + wave * (4 * QUAD_BYTES);
+    ring.lds_hi = ring.lds_lo + RING_BYTES;
+    ring.fetch_lds = ring.lds_lo;
+    ring.read_slot = NSLOT - 1;         // first ring_advance moves to slot 0
+    dma_slot(ring);
+    dma_slot(ring);
+    dma_slot(ring);
+
+    f32x16 acc[8];
+    f32x4 aq[8];                        // A-operand pipeline (gemm_part)
+    float h[HN];
+    float pe[KPE];
+    ring_advance(ring);                 // also publishes the side tables (barrier)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) aq[t] = ring_read(smem, ring, lane, t);
+
+    for (long long wgt = blockIdx.x; wgt < n_wg_tiles; wgt += gridDim.x) {
+        long long wt = wgt * 4 + wave;
+        const bool wave_active = wt < a.n_wtiles;
+        if (!wave_active) wt = a.n_wtiles - 1;
+        bool valid;
+        long long out_idx;
+        float de[KDE];
+        if constexpr (MODE == 0) {
+            const long long ray = wt / a.tpr;
+            const int sample = (int)(wt - ray * a.tpr) * 32 + col;
+            valid = wave_active && sample < a.S;
+            const int sc = sample < a.S ? sample : a.S - 1;
+            out_idx = ray * a.S + sc;
+            const float* rp = a.rays + ray * 6;
+            const float ox = rp[0], oy = rp[1], oz = rp[2], dx = rp[3], dy = rp[4], dz = rp[5];
+            const float zv = a.z[out_idx];
+            // pts = rays_o + rays_d * z : separate multiply and add (nerf_process.py:69-70), no contraction
+            const float p[3] = {ox + dx * zv, oy + dy * zv, oz + dz * zv};
+            const float amax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(p[0]), __builtin_fabsf(p[1])), __builtin_fabsf(p[2])) * (float)(1 << (LX - 1));
+            if (__builtin_expect(amax < SINCOS_FAST_LIMIT, 1)) encode_regs<LX, false>(pe, p, hh);
+            else encode_regs<LX, true>(pe, p, hh);               // huge or non-finite coordinates: libm path
+            // hoisted view-direction term of linear_d: scratch[n] = b_d[n] + sum_f Wd[n][W+f] * gamma(d/|d|)[f]
+            const float nrm = __builtin_sqrtf(dx * dx + dy * dy + dz * dz);
+            const float v[3] = {dx / nrm, dy / nrm, dz / nrm};
+            float g[IN_D];
+            g[0] = v[0]; g[1] = v[1]; g[2] = v[2];
+#pragma unroll
+            for (int k = 0; k < LD; ++k)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float y = v[c] * (float)(1 << k);
+                    g[3 + 6 * k + c] = sin_cos_fast(y, 0);       // |y| <= 2^(LD-1): no fallback needed
+                    g[3 + 6 * k + 3 + c] = sin_cos_fast(y, 1);
+                }
+            const float* wdt = side + a.o_wdir_t;
+            const float* bd = side + a.o_bias_d;
+#pragma unroll
+            for (int n0 = 0; n0 < W / 2; n0 += 64) {
+                const int n = n0 + lane;
+                float s = bd[n];
+#pragma unroll
+                for (int f = 0; f < IN_D; ++f) s = __builtin_fmaf(wdt[f * (W / 2) + n], g[f], s);
+                scratch[n] = s;
+            }
+        } else {
+            const long long p0 = wt * 32 + col;
+            valid = wave_active && p0 < a.n_pts;
+            out_idx = p0 < a.n_pts ? p0 : a.n_pts - 1;
+            const float* row = a.x + out_idx * (IN_X + IN_D);
+            gather_regs<LX>(pe, row, hh, true);
+            gather_regs<LD>(de, row + IN_X, hh, true);
+        }
+
+        // ---- trunk ----
+        acc_init<NT>(acc, side + a.o_bias_trunk, hh);
+        gemm_part<NT, KPE, NT>(acc, pe, aq, smem, ring, lane);
+#pragma unroll 1
+        for (int l = 1; l < a.D; ++l) {
+            acc_to_b<NT, true>(acc, h);
+            acc_init<NT>(acc, side + a.o_bias_trunk + l * W, hh);
+            if (l == a.skip_layer) gemm_part<NT, KPE, NT>(acc, pe, aq, smem, ring, lane);   // cat([gamma(x), h]) order
+            gemm_part<NT, HN, NT>(acc, h, aq, smem, ring, lane);
+        }
+        acc_to_b<NT, true>(acc, h);
+        // ---- density head (VALU dot over the trunk output) ----
+        const float dens = xhalf_sum(dot_half<HN>(h, side + a.o_dens_w, hh)) + side[a.o_dens_b];
+        // ---- feature layer (no activation) ----
+        acc_init<NT>(acc, side + a.o_bias_feat, hh);
+        gemm_part<NT, HN, NT / 2>(acc, h, aq, smem, ring, lane);
+        acc_to_b<NT, false>(acc, h);
+        // ---- view-direction layer ----
+        if constexpr (MODE == 0) {
+            acc_init<NT / 2>(acc, scratch, hh);
+            gemm_part<NT / 2, HN, NT>(acc, h, aq, smem, ring, lane);
+        } else {
+            acc_init<NT / 2>(acc, side + a.o_bias_d, hh);
+            gemm_part<NT / 2, HN, NT / 2>(acc, h, aq, smem, ring, lane);
+            gemm_part<NT / 2, KDE, NT>(acc, de, aq, smem, ring, lane);
+        }
+        float h2[HN / 2];
+        acc_to_b<NT / 2, true>(acc, h2);
+        // ---- colour head ----
+        const float* cw = side + a.o_color_w;
+        const float r0 = xhalf_sum(dot_half<HN / 2>(h2, cw, hh)) + side[a.o_color_b + 0];
+        const float r1 = xhalf_sum(dot_half<HN / 2>(h2, cw + W / 2, hh)) + side[a.o_color_b + 1];
+        const float r2 = xhalf_sum(dot_half<HN / 2>(h2, cw + W, hh)) + side[a.o_color_b + 2];
+        if (valid && hh == 0) {
+            f32x4 o; o[0] = r0; o[1] = r1; o[2] = r2; o[3] = dens;     // cat([rgb, density]) NeRF.py:51
+            *(f32x4*)(a.out + out_idx * 4) = o;
+        }
+    }
+    // the ring runs 3 slots ahead: let the last prefetches land before the workgroup's LDS is released
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static int check_net(const mi_nerf_net* net) {
+    MN_CHECK_ARG(net != nullptr, "net is NULL");
+    MN_CHECK_ARG(net->W == 256 || net->W == 128, "unsupported width W=%d (kernels exist for 128 and 256)", net->W);
+    MN_CHECK_ARG(net->D >= 2 && net->D <= 16, "unsupported depth D=%d", net->D);
+    MN_CHECK_ARG(net->L_x == 10 && net->L_d == 4, "unsupported encoding L_x=%d L_d=%d (kernels exist for 10/4)", net->L_x, net->L_d);
+    MN_CHECK_ARG(net->skip >= -1, "bad skip=%d", net->skip);
+    return MI_NERF_OK;
+}
+
+static int num_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
+template <int W, int MODE>
+static int launch(const MlpArgs& args, long long n_wtiles, hipStream_t st) {
+    const size_t lds = RING_BYTES + (size_t)args.side_floats * 4 + 4 * (W / 2) * 4;
+    MN_CHECK_ARG(lds <= 160 * 1024, "LDS budget exceeded: %zu bytes", lds);
+    auto kern = mlp_fp32_kernel<W, MODE, 10, 4>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        MN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    const long long n_wg = (n_wtiles + 3) / 4;
+    const int grid = (int)(n_wg < (long long)num_cus() ? n_wg : (long long)num_cus());
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, args);
+    MN_LAUNCH_CHECK("mlp_fp32_kernel");
+    return MI_NERF_OK;
+}
+
+static void fill_common(MlpArgs& a, const mi_nerf_net* net, const void* packed_dev, bool full_stream) {
+    const BlobLayout L = make_layout(net->D, net->W, net->skip, net->L_x, net->L_d);
+    a.stream = (const char*)packed_dev + L.stream_off;
+    a.side = (const float*)((const char*)packed_dev + L.side_off);
+    a.D = net->D;
+    a.skip_layer = (net->skip >= 0 && net->skip + 1 < net->D) ? net->skip + 1 : -1;
+    a.stream_bytes = full_stream ? L.stream_bytes_full : L.stream_bytes_hoist;
+    a.side_floats = L.side_floats;
+    a.o_bias_trunk = L.bias_trunk; a.o_bias_feat = L.bias_feat; a.o_bias_d = L.bias_d;
+    a.o_dens_w = L.dens_w; a.o_dens_b = L.dens_b; a.o_color_w = L.color_w; a.o_color_b = L.color_b;
+    a.o_wdir_t = L.wdir_t;
+}
+
+int mlp_rays_fp32(const mi_nerf_net* net, const void* packed_dev, const float* rays_dev, const float* z_dev,
+                  int64_t n_rays, int S, float* raw_dev, hipStream_t st) {
+    if (int rc = check_net(net)) return rc;
+    MN_CHECK_ARG(packed_dev && rays_dev && z_dev && raw_dev, "NULL device pointer");
+    MN_CHECK_ARG(n_rays >= 0 && S >= 1, "bad sizes n_rays=%lld S=%d", (long long)n_rays, S);
+    if (n_rays == 0) return MI_NERF_OK;
+    MlpArgs a{};
+    fill_common(a, net, packed_dev, false);
+    a.rays = rays_dev; a.z = z_dev; a.out = raw_dev; a.S = S; a.tpr = (S + 31) / 32;
+    a.n_wtiles = (long long)n_rays * a.tpr;
+    return net->W == 256 ? launch<256, 0>(a, a.n_wtiles, st) : launch<128, 0>(a, a.n_wtiles, st);
+}
+
+int mlp_embedded_fp32(const mi_nerf_net* net, const void* packed_dev, const float* x_dev, int64_t n, float* out_dev,
+                      hipStream_t st) {
+    if (int rc = check_net(net)) return rc;
+    MN_CHECK_ARG(packed_dev && x_dev && out_dev, "NULL device pointer");
+    MN_CHECK_ARG(n >= 0, "bad n=%lld", (long long)n);
+    if (n == 0) return MI_NERF_OK;
+    MlpArgs a{};
+    fill_common(a, net, packed_dev, true);
+    a.x = x_dev; a.out = out_dev; a.n_pts = n;
+    a.n_wtiles = (n + 31) / 32;
+    return net->W == 256 ? launch<256, 1>(a, a.n_wtiles, st) : launch<128, 1>(a, a.n_wtiles, st);
+}
+
+}  // namespace minerf

@@ -1,0 +1,101 @@
+// pack.cpp -- host-side weight packer: reference checkpoint layout -> kernel streaming order.
+//
+// Input: one NeRFModule's parameters as the reference stores them ([out,in] row-major fp32;
+// model/NeRF.py:24-30; checkpoint keys model_{coarse,fine}.* from train.py:105-114).
+// Output: the blob described in layout.h (header | MFMA A-operand stream | natural-order side tables).
+#include <hip/hip_runtime.h>
+#include <string.h>
+#include <vector>
+#include "common.h"
+#include "layout.h"
+
+namespace minerf {
+
+namespace {
+
+struct KStep { int lo, hi; };   // input column fed by lane half 0 / 1; -1 = zero pad
+
+// k-steps over an encoded 3-vector gamma(.) occupying columns [base, base+3+6L)
+std::vector<KStep> enc_ksteps(int L, int base) {
+    std::vector<KStep> ks;
+    for (int s = 0; s < 3 * L; ++s) {
+        const int k = s / 3, c = s % 3;
+        ks.push_back({base + 3 + 6 * k + c, base + 3 + 6 * k + 3 + c});   // (sin, cos) of 2^k p_c
+    }
+    ks.push_back({base + 0, base + 1});
+    ks.push_back({base + 2, -1});
+    while ((int)ks.size() < pe_ksteps(L)) ks.push_back({-1, -1});
+    return ks;
+}
+
+// k-steps over a W-wide activation held in accumulator layout, columns [base, base+W)
+std::vector<KStep> act_ksteps(int W, int base) {
+    std::vector<KStep> ks;
+    for (int t = 0; t < W / 32; ++t)
+        for (int r = 0; r < 16; ++r) {
+            const int f = 32 * t + (r & 3) + 8 * (r >> 2);
+            ks.push_back({base + f, base + f + 4});
+        }
+    return ks;
+}
+
+// Append one GEMM part to the stream: quads in (kq, T) order, padded to a whole number of slots.
+void emit_part(std::vector<float>& stream, const float* Wm, int n_out, int n_in, int NT, const std::vector<KStep>& ks) {
+    const int KQ = (int)ks.size() / 4;
+    for (int kq = 0; kq < KQ; ++kq)
+        for (int T = 0; T < NT; ++T)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 4; ++j) {
+                    const KStep& k = ks[4 * kq + j];
+                    const int col = (lane >> 5) ? k.hi : k.lo;
+                    const int n = 32 * T + (lane & 31);
+                    stream.push_back((col >= 0 && n < n_out) ? Wm[(size_t)n * n_in + col] : 0.0f);
+                }
+    const size_t slot_floats = SLOT_BYTES / 4;
+    while (stream.size() % slot_floats) stream.push_back(0.0f);
+}
+
+}  // namespace
+
+int pack_fp32(const mi_nerf_net* net, const mi_nerf_params* p, void* blob, size_t blob_bytes) {
+    const int D = net->D, W = net->W, NT = W / 32;
+    const int in_x = 3 + 6 * net->L_x, in_d = 3 + 6 * net->L_d;
+    const BlobLayout L = make_layout(D, W, net->skip, net->L_x, net->L_d);
+    MN_CHECK_ARG(blob_bytes >= L.total_bytes, "blob too small: %zu < %u", blob_bytes, L.total_bytes);
+    memset(blob, 0, L.total_bytes);
+
+    std::vector<float> stream;
+    stream.reserve(L.stream_bytes_full / 4);
+    emit_part(stream, p->linear_x_w[0], W, in_x, NT, enc_ksteps(net->L_x, 0));
+    for (int l = 1; l < D; ++l) {
+        const bool cat = (net->skip >= 0 && l == net->skip + 1);
+        const int n_in = cat ? W + in_x : W;
+        if (cat) emit_part(stream, p->linear_x_w[l], W, n_in, NT, enc_ksteps(net->L_x, 0));   // [gamma(x), h]
+        emit_part(stream, p->linear_x_w[l], W, n_in, NT, act_ksteps(W, cat ? in_x : 0));
+    }
+    emit_part(stream, p->linear_feat_w, W, W, NT, act_ksteps(W, 0));
+    emit_part(stream, p->linear_d_w, W / 2, W + in_d, NT / 2, act_ksteps(W, 0));                // [feature, gamma(d)]
+    MN_CHECK_ARG(stream.size() * 4 == L.stream_bytes_hoist, "internal: hoisted stream %zu != %u", stream.size() * 4, L.stream_bytes_hoist);
+    emit_part(stream, p->linear_d_w, W / 2, W + in_d, NT / 2, enc_ksteps(net->L_d, W));
+    MN_CHECK_ARG(stream.size() * 4 == L.stream_bytes_full, "internal: full stream %zu != %u", stream.size() * 4, L.stream_bytes_full);
+
+    uint32_t* hdr = (uint32_t*)blob;
+    hdr[0] = BLOB_MAGIC; hdr[1] = 1; hdr[2] = D; hdr[3] = W; hdr[4] = (uint32_t)net->skip; hdr[5] = net->L_x; hdr[6] = net->L_d;
+    hdr[7] = L.stream_off; hdr[8] = L.stream_bytes_hoist; hdr[9] = L.stream_bytes_full; hdr[10] = L.side_off; hdr[11] = L.side_floats;
+    hdr[12] = 4;   // stream element bytes
+    memcpy((char*)blob + L.stream_off, stream.data(), L.stream_bytes_full);
+
+    float* side = (float*)((char*)blob + L.side_off);
+    for (int l = 0; l < D; ++l) memcpy(side + L.bias_trunk + (size_t)l * W, p->linear_x_b[l], W * 4);
+    memcpy(side + L.bias_feat, p->linear_feat_b, W * 4);
+    memcpy(side + L.bias_d, p->linear_d_b, (W / 2) * 4);
+    memcpy(side + L.dens_w, p->linear_density_w, W * 4);
+    side[L.dens_b] = p->linear_density_b[0];
+    memcpy(side + L.color_w, p->linear_color_w, 3 * (W / 2) * 4);
+    memcpy(side + L.color_b, p->linear_color_b, 3 * 4);
+    for (int f = 0; f < in_d; ++f)
+        for (int n = 0; n < W / 2; ++n) side[L.wdir_t + (size_t)f * (W / 2) + n] = p->linear_d_w[(size_t)n * (W + in_d) + W + f];
+    return MI_NERF_OK;
+}
+
+}  // namespace minerf

@@ -1,0 +1,483 @@
+// stages.hip -- the non-GEMM stages of the render path as HBM-bound / wavefront kernels (gfx950).
+//
+//   make_o_d            rays.py:20-34               one thread per pixel, coalesced AoS stores
+//   ndc_rays            nerf_process.py:8-28        one thread per ray
+//   fill_uniform        stand-in for torch.rand at nerf_process.py:58,162 (counter-based, shard invariant)
+//   stratified_z        nerf_process.py:42-60       one thread per sample
+//   embed               nerf_process.py:36-39,69-85 + model/PositionalEncoding.py:29-30, one thread per output
+//                       channel (coalesced 4-byte stores, the tensor is write-only traffic: 360 B/point)
+//   composite           nerf_process.py:89-140      one 64-lane wavefront per ray: per-lane chunk product,
+//                       Kogge-Stone exclusive prefix product across lanes, butterfly sums
+//   sample_pdf / fine_z nerf_process.py:144-182, :62-67  one wavefront per ray: prefix-sum CDF in LDS,
+//                       branch-free upper_bound, rank sort of the merged depths
+//
+// Arithmetic follows the reference's operation order in fp32 with IEEE division and no FMA contraction
+// (the file is compiled with -ffp-contract=off); FMAs appear only where written explicitly.
+#include "common.h"
+
+namespace minerf {
+
+// ------------------------------------------------------------------------------------------------
+// ray generation
+// ------------------------------------------------------------------------------------------------
+struct CamArgs {
+    float fx, fy, cx, cy;
+    float r[9];     // rotation, row-major
+    float t[3];     // translation
+};
+
+__device__ __forceinline__ void pixel_ray(const CamArgs& c, int x, int y, float (&d)[3]) {
+    const float dx = ((float)x - c.cx) / c.fx;          // rays.py:28
+    const float dy = -((float)y - c.cy) / c.fy;         // rays.py:29
+    const float dz = -1.0f;                              // rays.py:30
+#pragma unroll
+    for (int i = 0; i < 3; ++i)                          // dirs @ R^T  (rays.py:32)
+        d[i] = __builtin_fmaf(dz, c.r[3 * i + 2], __builtin_fmaf(dy, c.r[3 * i + 1], dx * c.r[3 * i + 0]));
+}
+
+__global__ __launch_bounds__(256) void make_o_d_kernel(CamArgs c, int W, int row0, long long n, float* __restrict__ o,
+                                                        float* __restrict__ dout) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int y = (int)(i / W) + row0, x = (int)(i % W);
+    float d[3];
+    pixel_ray(c, x, y, d);
+    dout[3 * i + 0] = d[0]; dout[3 * i + 1] = d[1]; dout[3 * i + 2] = d[2];
+    if (o) { o[3 * i + 0] = c.t[0]; o[3 * i + 1] = c.t[1]; o[3 * i + 2] = c.t[2]; }
+}
+
+__global__ __launch_bounds__(256) void make_o_d_pixels_kernel(CamArgs c, int W, const long long* __restrict__ pix,
+                                                               long long n, float* __restrict__ o, float* __restrict__ dout) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const long long p = pix[i];
+    float d[3];
+    pixel_ray(c, (int)(p % W), (int)(p / W), d);
+    dout[3 * i + 0] = d[0]; dout[3 * i + 1] = d[1]; dout[3 * i + 2] = d[2];
+    if (o) { o[3 * i + 0] = c.t[0]; o[3 * i + 1] = c.t[1]; o[3 * i + 2] = c.t[2]; }
+}
+
+static CamArgs cam_args(const float k4[4], const float pose12[12]) {
+    CamArgs c;
+    c.fx = k4[0]; c.fy = k4[1]; c.cx = k4[2]; c.cy = k4[3];
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) c.r[3 * i + j] = pose12[4 * i + j];
+        c.t[i] = pose12[4 * i + 3];
+    }
+    return c;
+}
+
+// ------------------------------------------------------------------------------------------------
+// NDC warp
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ndc_kernel(float sx, float sy, float near_, float two_near, const float* __restrict__ oin,
+                                                   long long os, const float* __restrict__ din, long long ds, long long n,
+                                                   float* __restrict__ oo, float* __restrict__ dd) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float ox = oin[i * os + 0], oy = oin[i * os + 1], oz = oin[i * os + 2];
+    const float dx = din[i * ds + 0], dy = din[i * ds + 1], dz = din[i * ds + 2];
+    const float t = -(near_ + oz) / dz;                  // nerf_process.py:11
+    ox = ox + t * dx; oy = oy + t * dy; oz = oz + t * dz; // :12
+    const float ox_oz = ox / oz, oy_oz = oy / oz;
+    oo[3 * i + 0] = sx * ox / oz;                        // :15  (scale*o_x)/o_z
+    oo[3 * i + 1] = sy * oy / oz;                        // :16
+    oo[3 * i + 2] = 1.0f + two_near / oz;                // :17
+    dd[3 * i + 0] = sx * (dx / dz - ox_oz);              // :19-20
+    dd[3 * i + 1] = sy * (dy / dz - oy_oz);              // :21-22
+    dd[3 * i + 2] = -two_near / oz;                      // :23
+}
+
+// ------------------------------------------------------------------------------------------------
+// uniforms and stratified depths
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fill_uniform_kernel(uint32_t seed, uint32_t stream_id, long long ray0, long long total,
+                                                            int S, float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const long long r = i / S;
+    out[i] = counter_uniform(seed, stream_id, (uint32_t)(ray0 + r), (uint32_t)(i - r * S));
+}
+
+// torch.linspace(0,1,S)[i] in fp32 (symmetric fill: ATen RangeFactories) and z = near*(1-t) + far*t
+__device__ __forceinline__ float strat_edge(int i, int S, float step, float near_, float far_) {
+    const float t = (i < S / 2) ? step * (float)i : 1.0f - step * (float)(S - 1 - i);
+    return near_ * (1.0f - t) + far_ * t;               // nerf_process.py:53
+}
+
+__global__ __launch_bounds__(256) void stratified_kernel(long long total, int S, float near_, float far_, float step,
+                                                          const float* __restrict__ t_rand, float* __restrict__ z) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int i = (int)(idx % S);
+    const float zi = strat_edge(i, S, step, near_, far_);
+    const float lower = (i == 0) ? zi : 0.5f * (zi + strat_edge(i - 1, S, step, near_, far_));       // :55,57
+    const float upper = (i == S - 1) ? zi : 0.5f * (strat_edge(i + 1, S, step, near_, far_) + zi);   // :55,56
+    z[idx] = lower + (upper - lower) * t_rand[idx];     // :60
+}
+
+// ------------------------------------------------------------------------------------------------
+// network-input assembly (unfused path, for pre_process parity)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ rays, const float* __restrict__ z, long long n_pts,
+                                                     int S, int L_x, int L_d, float* __restrict__ out) {
+    const int in_x = 3 + 6 * L_x, ch_total = in_x + 3 + 6 * L_d;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n_pts * ch_total) return;
+    const long long pt = idx / ch_total;
+    int ch = (int)(idx - pt * ch_total);
+    const float* rp = rays + (pt / S) * 6;
+    float base;
+    if (ch < in_x) {
+        const int c = (ch < 3) ? ch : (ch - 3) % 3;
+        base = rp[c] + rp[3 + c] * z[pt];                                // nerf_process.py:69-70
+    } else {
+        ch -= in_x;
+        const float dx = rp[3], dy = rp[4], dz = rp[5];
+        const float nrm = __builtin_sqrtf(dx * dx + dy * dy + dz * dz);  // :39
+        const int c = (ch < 3) ? ch : (ch - 3) % 3;
+        base = rp[3 + c] / nrm;
+    }
+    float v = base;
+    if (ch >= 3) {
+        const int k = (ch - 3) / 6, is_cos = ((ch - 3) % 6) >= 3;        // PositionalEncoding.py:20-24
+        const float y = base * (float)(1 << k);
+        v = (__builtin_fabsf(y) < SINCOS_FAST_LIMIT) ? sin_cos_fast(y, is_cos) : sin_cos_slow(y, is_cos);
+    }
+    out[idx] = v;
+}
+
+// gamma(x) for arbitrary 3-vectors: the closure returned by get_positional_encoder (PositionalEncoding.py:33-36)
+__global__ __launch_bounds__(256) void posenc_kernel(const float* __restrict__ x, long long n, int L, float* __restrict__ out) {
+    const int ch_total = 3 + 6 * L;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n * ch_total) return;
+    const long long pt = idx / ch_total;
+    const int ch = (int)(idx - pt * ch_total);
+    const int c = (ch < 3) ? ch : (ch - 3) % 3;
+    const float base = x[pt * 3 + c];
+    float v = base;
+    if (ch >= 3) {
+        const int k = (ch - 3) / 6, is_cos = ((ch - 3) % 6) >= 3;
+        const float y = base * (float)(1 << k);
+        v = (__builtin_fabsf(y) < SINCOS_FAST_LIMIT) ? sin_cos_fast(y, is_cos) : sin_cos_slow(y, is_cos);
+    }
+    out[idx] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// wave helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+// exclusive prefix product / sum across the 64 lanes (Kogge-Stone on __shfl_up)
+__device__ __forceinline__ float wave_excl_prod(float v, int lane) {
+    float inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const float o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc *= o;
+    }
+    const float e = __shfl_up(inc, 1, 64);
+    return lane == 0 ? 1.0f : e;
+}
+__device__ __forceinline__ float wave_excl_sum(float v, int lane) {
+    float inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const float o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    const float e = __shfl_up(inc, 1, 64);
+    return lane == 0 ? 0.0f : e;
+}
+
+// ------------------------------------------------------------------------------------------------
+// alpha compositing: one wavefront per ray, lane l owns samples [l*C, (l+1)*C)
+// ------------------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(256) void composite_kernel(const float* __restrict__ raw, const float* __restrict__ z,
+                                                         const float* __restrict__ rays, int ray_stride, long long n, int S,
+                                                         float* __restrict__ rgb_o, float* __restrict__ disp_o,
+                                                         float* __restrict__ acc_o, float* __restrict__ w_o,
+                                                         float* __restrict__ depth_o) {
+    const int lane = threadIdx.x & 63;
+    const long long ray = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= n) return;
+    const float* dp = rays + ray * ray_stride + (ray_stride == 6 ? 3 : 0);
+    const float dx = dp[0], dy = dp[1], dz = dp[2];
+    const float dnorm = __builtin_sqrtf(dx * dx + dy * dy + dz * dz);     // nerf_process.py:101
+    const float* zr = z + ray * S;
+    const f32x4* rr = (const f32x4*)(raw + ray * S * 4);
+
+    float alpha[C], zv[C], cr[C], cg[C], cb[C];
+    float local = 1.0f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const int s = lane * C + c;
+        const bool in = s < S;
+        const int sc = in ? s : S - 1;
+        const f32x4 v = rr[sc];
+        zv[c] = zr[sc];
+        float dist = (s + 1 < S) ? (zr[s + 1] - zv[c]) : 1e10f;           // :93-97
+        dist = dist * dnorm;                                               // :101
+        const float sig = __builtin_fmaxf(v[3], 0.0f);                     // relu, :91
+        float a = 1.0f - expf(-sig * dist);                                // :92
+        if (!in) a = 0.0f;
+        alpha[c] = a;
+        cr[c] = 1.0f / (1.0f + expf(-v[0]));                               // sigmoid, :104
+        cg[c] = 1.0f / (1.0f + expf(-v[1]));
+        cb[c] = 1.0f / (1.0f + expf(-v[2]));
+        local *= in ? (1.0f - a + 1e-10f) : 1.0f;                          // :110
+    }
+    float T = wave_excl_prod(local, lane);                                 // transmittance entering this lane's chunk
+    float sw = 0.f, sr = 0.f, sg = 0.f, sb = 0.f, sd = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const int s = lane * C + c;
+        const float w = alpha[c] * T;                                      // :111
+        if (s < S) {
+            if (w_o) w_o[ray * S + s] = w;
+            sw += w; sr += w * cr[c]; sg += w * cg[c]; sb += w * cb[c]; sd += w * zv[c];
+        }
+        T *= (1.0f - alpha[c] + 1e-10f);
+    }
+    sw = wave_sum(sw); sr = wave_sum(sr); sg = wave_sum(sg); sb = wave_sum(sb); sd = wave_sum(sd);
+    if (lane == 0) {
+        const float q = sd / sw;                                           // depth / acc
+        const float m = (q != q) ? q : __builtin_fmaxf(1e-10f, q);         // torch.max propagates NaN (:124)
+        float disp = 1.0f / m;
+        if (disp != disp) disp = 0.0f;                                     // :126
+        if (disp > 5.0f) disp = 5.0f;                                      // :132-134
+        const float bg = 1.0f - sw;                                        // :138 white background, always
+        rgb_o[ray * 3 + 0] = sr + bg; rgb_o[ray * 3 + 1] = sg + bg; rgb_o[ray * 3 + 2] = sb + bg;
+        disp_o[ray] = disp;
+        if (acc_o) acc_o[ray] = sw;
+        if (depth_o) depth_o[ray] = sd;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// inverse-CDF sampling, one wavefront per ray.  cdf/bins live in this wave's LDS slice.
+// ------------------------------------------------------------------------------------------------
+// Build cdf[0..B) from weights w[0..B-1) (nerf_process.py:150-154).  Lane l owns entries [l*C, (l+1)*C).
+__device__ __forceinline__ void build_cdf(const float* __restrict__ w, int nw, float* cdf, int lane) {
+    const int C = (nw + 63) / 64;
+    float part = 0.f;
+    for (int c = 0; c < C; ++c) {
+        const int k = lane * C + c;
+        if (k < nw) part += w[k] + 1e-5f;                                  // :150
+    }
+    const float total = wave_sum(part);
+    float run = 0.f, lsum = 0.f;
+    for (int c = 0; c < C; ++c) {
+        const int k = lane * C + c;
+        if (k < nw) lsum += (w[k] + 1e-5f) / total;                        // pdf, :151
+    }
+    run = wave_excl_sum(lsum, lane);
+    if (lane == 0) cdf[0] = 0.0f;                                          // :154
+    for (int c = 0; c < C; ++c) {
+        const int k = lane * C + c;
+        if (k < nw) { run += (w[k] + 1e-5f) / total; cdf[k + 1] = run; }   // cumsum, :152
+    }
+}
+
+__device__ __forceinline__ float invert_cdf(const float* cdf, const float* bins, int B, float u) {
+    // searchsorted(cdf, u, right=True): number of entries <= u   (:167)
+    int lo = 0, len = B;
+    while (len > 0) {
+        const int half = len >> 1;
+        const bool go = cdf[lo + half] <= u;
+        lo = go ? lo + half + 1 : lo;
+        len = go ? len - half - 1 : half;
+    }
+    const int below = lo - 1 > 0 ? lo - 1 : 0;                             // :168
+    const int above = lo < B - 1 ? lo : B - 1;                             // :169
+    const float c0 = cdf[below], c1 = cdf[above];
+    float denom = c1 - c0;                                                 // :178
+    if (denom < 1e-5f) denom = 1.0f;                                       // :179
+    const float t = (u - c0) / denom;                                      // :180
+    const float b0 = bins[below], b1 = bins[above];
+    return b0 + t * (b1 - b0);                                             // :181
+}
+
+__device__ __forceinline__ float det_u(int j, int N) {                     // torch.linspace(0,1,N)[j], :158
+    if (N == 1) return 0.0f;
+    const float step = 1.0f / (float)(N - 1);
+    return (j < N / 2) ? step * (float)j : 1.0f - step * (float)(N - 1 - j);
+}
+
+__global__ __launch_bounds__(256) void sample_pdf_kernel(const float* __restrict__ bins, const float* __restrict__ weights,
+                                                          long long n, int B, int N, int det, const float* __restrict__ u,
+                                                          float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long long ray = (long long)blockIdx.x * 4 + wv;
+    if (ray >= n) return;
+    float* cdf = lds + wv * 2 * B;
+    float* bn = cdf + B;
+    for (int k = lane; k < B; k += 64) bn[k] = bins[ray * B + k];
+    build_cdf(weights + ray * (B - 1), B - 1, cdf, lane);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    for (int j = lane; j < N; j += 64) {
+        const float uu = det ? det_u(j, N) : u[ray * N + j];
+        out[ray * N + j] = invert_cdf(cdf, bn, B, uu);
+    }
+}
+
+// fine branch: bins = mid(z_c), weights = weights_c[1:-1], then sort(cat(z_c, samples))   (:63-67)
+__global__ __launch_bounds__(256) void fine_z_kernel(const float* __restrict__ z_c, const float* __restrict__ w_c, long long n,
+                                                      int Sc, int Nf, int det, const float* __restrict__ u,
+                                                      float* __restrict__ z_f, float* __restrict__ z_samp) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long long ray = (long long)blockIdx.x * 4 + wv;
+    if (ray >= n) return;
+    const int B = Sc - 1, St = Sc + Nf;
+    float* cdf = lds + wv * (2 * B + St);
+    float* bn = cdf + B;
+    float* all = bn + B;
+    const float* zr = z_c + ray * Sc;
+    for (int k = lane; k < Sc; k += 64) all[k] = zr[k];
+    for (int k = lane; k < B; k += 64) bn[k] = 0.5f * (zr[k + 1] + zr[k]);                 // :63
+    build_cdf(w_c + ray * Sc + 1, Sc - 2, cdf, lane);                                       // weights[..., 1:-1]
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    for (int j = lane; j < Nf; j += 64) {
+        const float uu = det ? det_u(j, Nf) : u[ray * Nf + j];
+        const float s = invert_cdf(cdf, bn, B, uu);
+        all[Sc + j] = s;
+        if (z_samp) z_samp[ray * Nf + j] = s;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // rank sort (values only matter, ties broken by position): rank = #smaller + #equal-before
+    for (int e = lane; e < St; e += 64) {
+        const float v = all[e];
+        int rank = 0;
+        for (int k = 0; k < St; ++k) {
+            const float o = all[k];
+            rank += (o < v || (o == v && k < e)) ? 1 : 0;
+        }
+        z_f[ray * St + rank] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host entry points (called from api.cpp)
+// ------------------------------------------------------------------------------------------------
+static inline unsigned blocks_for(long long n, int per_block) { return (unsigned)((n + per_block - 1) / per_block); }
+
+int stage_make_o_d(int W, int H, const float k4[4], const float pose12[12], int row0, int n_rows, float* o, float* d,
+                   hipStream_t st) {
+    MN_CHECK_ARG(W > 0 && H > 0 && row0 >= 0 && n_rows >= 0 && row0 + n_rows <= H, "bad image window W=%d H=%d rows [%d,+%d)", W, H, row0, n_rows);
+    MN_CHECK_ARG(d != nullptr, "rays_d output is NULL");
+    const long long n = (long long)n_rows * W;
+    if (n == 0) return MI_NERF_OK;
+    hipLaunchKernelGGL(make_o_d_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, st, cam_args(k4, pose12), W, row0, n, o, d);
+    MN_LAUNCH_CHECK("make_o_d_kernel");
+    return MI_NERF_OK;
+}
+
+int stage_make_o_d_pixels(int W, int H, const float k4[4], const float pose12[12], const int64_t* pix, int64_t n, float* o,
+                          float* d, hipStream_t st) {
+    MN_CHECK_ARG(W > 0 && H > 0 && n >= 0 && d != nullptr && (pix != nullptr || n == 0), "bad arguments");
+    if (n == 0) return MI_NERF_OK;
+    hipLaunchKernelGGL(make_o_d_pixels_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, st, cam_args(k4, pose12), W,
+                       (const long long*)pix, (long long)n, o, d);
+    MN_LAUNCH_CHECK("make_o_d_pixels_kernel");
+    return MI_NERF_OK;
+}
+
+int stage_ndc(int H, int W, float focal, float near_, const float* o_in, int64_t os, const float* d_in, int64_t ds, int64_t n,
+              float* o_out, float* d_out, hipStream_t st) {
+    MN_CHECK_ARG(H > 0 && W > 0 && n >= 0 && o_in && d_in && o_out && d_out, "bad arguments");
+    if (n == 0) return MI_NERF_OK;
+    // python-float (double) scale factors, rounded once to fp32 where they meet the tensors (nerf_process.py:15-23)
+    const float sx = (float)(-1.0 / ((double)W / (2.0 * (double)focal)));
+    const float sy = (float)(-1.0 / ((double)H / (2.0 * (double)focal)));
+    const float two_near = (float)(2.0 * (double)near_);
+    hipLaunchKernelGGL(ndc_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, st, sx, sy, near_, two_near, o_in, (long long)os, d_in,
+                       (long long)ds, (long long)n, o_out, d_out);
+    MN_LAUNCH_CHECK("ndc_kernel");
+    return MI_NERF_OK;
+}
+
+int stage_fill_uniform(uint32_t seed, uint32_t stream_id, int64_t ray0, int64_t n_rays, int S, float* out, hipStream_t st) {
+    MN_CHECK_ARG(n_rays >= 0 && S >= 0 && (out || n_rays * S == 0), "bad arguments");
+    const long long total = (long long)n_rays * S;
+    if (total == 0) return MI_NERF_OK;
+    hipLaunchKernelGGL(fill_uniform_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, st, seed, stream_id, (long long)ray0, total, S, out);
+    MN_LAUNCH_CHECK("fill_uniform_kernel");
+    return MI_NERF_OK;
+}
+
+int stage_stratified(int64_t n_rays, int S, float near_, float far_, const float* t_rand, float* z, hipStream_t st) {
+    MN_CHECK_ARG(n_rays >= 0 && S >= 1 && t_rand && z, "bad arguments");
+    const long long total = (long long)n_rays * S;
+    if (total == 0) return MI_NERF_OK;
+    const float step = S > 1 ? 1.0f / (float)(S - 1) : 0.0f;
+    hipLaunchKernelGGL(stratified_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, st, total, S, near_, far_, step, t_rand, z);
+    MN_LAUNCH_CHECK("stratified_kernel");
+    return MI_NERF_OK;
+}
+
+int stage_embed(const float* rays, const float* z, int64_t n_rays, int S, int L_x, int L_d, float* out, hipStream_t st) {
+    MN_CHECK_ARG(n_rays >= 0 && S >= 1 && L_x >= 0 && L_x <= 20 && L_d >= 0 && L_d <= 20 && rays && z && out, "bad arguments");
+    const long long n_pts = (long long)n_rays * S;
+    const long long total = n_pts * (6 + 6 * L_x + 6 * L_d);
+    if (total == 0) return MI_NERF_OK;
+    hipLaunchKernelGGL(embed_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, st, rays, z, n_pts, S, L_x, L_d, out);
+    MN_LAUNCH_CHECK("embed_kernel");
+    return MI_NERF_OK;
+}
+
+int stage_posenc(const float* x, int64_t n, int L, float* out, hipStream_t st) {
+    MN_CHECK_ARG(n >= 0 && L >= 0 && L <= 20 && x && out, "bad arguments");
+    const long long total = (long long)n * (3 + 6 * L);
+    if (total == 0) return MI_NERF_OK;
+    hipLaunchKernelGGL(posenc_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, st, x, (long long)n, L, out);
+    MN_LAUNCH_CHECK("posenc_kernel");
+    return MI_NERF_OK;
+}
+
+int stage_composite(const float* raw, const float* z, const float* rays, int ray_stride, int64_t n, int S, float* rgb, float* disp,
+                    float* acc, float* weights, float* depth, hipStream_t st) {
+    MN_CHECK_ARG(n >= 0 && S >= 1 && S <= 1024 && raw && z && rays && rgb && disp, "bad arguments (S=%d)", S);
+    MN_CHECK_ARG(ray_stride == 3 || ray_stride == 6, "ray_stride must be 3 or 6");
+    if (n == 0) return MI_NERF_OK;
+    const dim3 grid(blocks_for(n, 4)), block(256);
+    const int C = (S + 63) / 64;
+#define MN_COMP(CC) hipLaunchKernelGGL(composite_kernel<CC>, grid, block, 0, st, raw, z, rays, ray_stride, (long long)n, S, rgb, disp, acc, weights, depth)
+    if (C == 1) MN_COMP(1); else if (C == 2) MN_COMP(2); else if (C == 3) MN_COMP(3); else if (C == 4) MN_COMP(4);
+    else if (C <= 8) MN_COMP(8); else MN_COMP(16);
+#undef MN_COMP
+    MN_LAUNCH_CHECK("composite_kernel");
+    return MI_NERF_OK;
+}
+
+int stage_sample_pdf(const float* bins, const float* weights, int64_t n, int B, int N, int det, const float* u, float* out,
+                     hipStream_t st) {
+    MN_CHECK_ARG(n >= 0 && B >= 2 && B <= 4096 && N >= 1 && bins && weights && out && (det || u), "bad arguments (B=%d N=%d)", B, N);
+    if (n == 0) return MI_NERF_OK;
+    hipLaunchKernelGGL(sample_pdf_kernel, dim3(blocks_for(n, 4)), dim3(256), (size_t)4 * 2 * B * sizeof(float), st, bins, weights,
+                       (long long)n, B, N, det, u, out);
+    MN_LAUNCH_CHECK("sample_pdf_kernel");
+    return MI_NERF_OK;
+}
+
+int stage_fine_z(const float* z_c, const float* w_c, int64_t n, int Sc, int Nf, int det, const float* u, float* z_f, float* z_samp,
+                 hipStream_t st) {
+    MN_CHECK_ARG(n >= 0 && Sc >= 3 && Nf >= 1 && Sc + Nf <= 4096 && z_c && w_c && z_f && (det || u), "bad arguments (Sc=%d Nf=%d)", Sc, Nf);
+    if (n == 0) return MI_NERF_OK;
+    const size_t lds = (size_t)4 * (2 * (Sc - 1) + Sc + Nf) * sizeof(float);
+    hipLaunchKernelGGL(fine_z_kernel, dim3(blocks_for(n, 4)), dim3(256), lds, st, z_c, w_c, (long long)n, Sc, Nf, det, u, z_f, z_samp);
+    MN_LAUNCH_CHECK("fine_z_kernel");
+    return MI_NERF_OK;
+}
+
+}  // namespace minerf

@@ -1,0 +1,60 @@
+"""NeRF coarse+fine MLP pair -- drop-in for the reference's model/NeRF.py:10-78.
+
+Same constructor arguments, same sub-module and parameter names (so ``load_state_dict`` accepts the
+reference's checkpoints, train.py:105-114), same ``forward(x, is_fine)`` contract.  The forward pass
+is the hand-written MFMA kernel (``mi_nerf_mlp_embedded``): parameters are packed into the kernel's
+streaming layout on first use and re-packed only when they change.  Forward-only (the callers on the
+path run under ``torch.no_grad()``, test.py:36,140).
+"""
+from __future__ import annotations
+
+from typing import Sequence
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .._lib import MiNerfError, as_f32_dev
+
+
+class NeRFModule(nn.Module):
+    def __init__(self, D: int, W: int, input_ch: int, input_ch_d: int, skips: Sequence[int] = (4,)):
+        super().__init__()
+        self.D, self.W = D, W
+        self.input_ch_x, self.input_ch_d = input_ch, input_ch_d
+        self.skips = list(skips)
+        # NeRF.py:24-30 -- layer i+1 takes [gamma(x), h] iff i is a skip index
+        self.linear_x = nn.ModuleList(
+            [nn.Linear(input_ch, W)] + [nn.Linear(W + input_ch if i in self.skips else W, W) for i in range(D - 1)])
+        self.linear_d = nn.Linear(input_ch_d + W, W // 2)
+        self.linear_feat = nn.Linear(W, W)
+        self.linear_density = nn.Linear(W, 1)
+        self.linear_color = nn.Linear(W // 2, 3)
+
+    def forward(self, x):
+        raise MiNerfError("call the parent NeRF module (model(x, is_fine)); the packed kernel needs both nets' context")
+
+
+class NeRF(nn.Module):
+    def __init__(self, D: int, W: int, input_ch: int, input_ch_d: int, skips: Sequence[int] = (4,), gt_camera_param=None, device=None):
+        super().__init__()
+        self.model_coarse = NeRFModule(D, W, input_ch, input_ch_d, skips)
+        self.model_fine = NeRFModule(D, W, input_ch, input_ch_d, skips)
+        self.apply(self._init_weights)                                   # NeRF.py:60,63-65
+        self.gt_intrinsic, self.gt_extrinsic = gt_camera_param if gt_camera_param is not None else (None, None)
+
+    def _init_weights(self, m):
+        if isinstance(m, nn.Linear):
+            nn.init.xavier_uniform_(m.weight)
+
+    def get_camera_gt(self):
+        return self.gt_intrinsic, self.gt_extrinsic
+
+    def forward(self, x, is_fine: bool = False):
+        """x [n, input_ch + input_ch_d] -> [n, 4] = cat([rgb_raw, density_raw]) (NeRF.py:51,70-78)."""
+        from ..weights import packed_for
+        packed = packed_for(self)
+        x = as_f32_dev(x, packed.device)
+        lead = x.shape[:-1]
+        out = ops.mlp_embedded(packed.net, packed.blob(is_fine), x.reshape(-1, x.shape[-1]))
+        return out.reshape(*lead, 4)

@@ -1,0 +1,303 @@
+"""Tensor-level wrappers over the C ABI: allocate outputs with torch, hand raw pointers across.
+
+Every function launches on ``torch.cuda.current_stream`` of the tensors' device and returns
+immediately (no host synchronisation).  PyTorch is used for device memory and streams only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from ._lib import MiNerfError, Net, RenderCfg, WorkspaceLayout, check, dev_ptr, lib, stream_ptr
+
+
+def _guard(device):
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise MiNerfError(f"tensors must live on a HIP device (got {device}); this path has no CPU fallback")
+    return torch.cuda.device(device)
+
+
+def make_net(D: int, W: int, skip: int = 4, L_x: int = 10, L_d: int = 4) -> Net:
+    return Net(D, W, skip, L_x, L_d)
+
+
+# ------------------------------------------------------------------------------------------------
+# weights
+# ------------------------------------------------------------------------------------------------
+def pack_module(sd: Dict[str, "np.ndarray | torch.Tensor"], prefix: str, net: Net, bf16: bool = False) -> torch.Tensor:
+    """Pack one NeRFModule (keys ``{prefix}linear_x.{i}.weight`` ...; model/NeRF.py:24-30) into the
+    kernels' streaming layout.  Returns a CPU uint8 tensor; copy it to the device once."""
+    def arr(key):
+        v = sd[prefix + key]
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        return np.ascontiguousarray(v, dtype=np.float32)
+
+    in_x, in_d, W, D = 3 + 6 * net.L_x, 3 + 6 * net.L_d, net.W, net.D
+    keep = []
+    def ptr(a, shape):
+        if tuple(a.shape) != tuple(shape):
+            raise MiNerfError(f"parameter shape {a.shape} != expected {shape}")
+        keep.append(a)
+        return a.ctypes.data_as(C.c_void_p)
+
+    wx = (C.c_void_p * D)()
+    bx = (C.c_void_p * D)()
+    for l in range(D):
+        fan_in = in_x if l == 0 else (W + in_x if (net.skip >= 0 and l == net.skip + 1) else W)
+        wx[l] = ptr(arr(f"linear_x.{l}.weight"), (W, fan_in))
+        bx[l] = ptr(arr(f"linear_x.{l}.bias"), (W,))
+    p = L.Params(wx, bx,
+                 ptr(arr("linear_density.weight"), (1, W)), ptr(arr("linear_density.bias"), (1,)),
+                 ptr(arr("linear_feat.weight"), (W, W)), ptr(arr("linear_feat.bias"), (W,)),
+                 ptr(arr("linear_d.weight"), (W // 2, W + in_d)), ptr(arr("linear_d.bias"), (W // 2,)),
+                 ptr(arr("linear_color.weight"), (3, W // 2)), ptr(arr("linear_color.bias"), (3,)))
+    size_fn, pack_fn = ((lib().mi_nerf_packed_bytes_bf16, lib().mi_nerf_pack_weights_bf16) if bf16
+                        else (lib().mi_nerf_packed_bytes, lib().mi_nerf_pack_weights))
+    nbytes = size_fn(C.byref(net))
+    if nbytes == 0:
+        check(1, "mi_nerf_packed_bytes")
+    blob = torch.empty(nbytes, dtype=torch.uint8)
+    check(pack_fn(C.byref(net), C.byref(p), blob.data_ptr(), nbytes), "mi_nerf_pack_weights")
+    return blob
+
+
+# ------------------------------------------------------------------------------------------------
+# rays
+# ------------------------------------------------------------------------------------------------
+def _cam(K, pose) -> Tuple[C.Array, C.Array]:
+    k = K.detach().cpu().numpy() if isinstance(K, torch.Tensor) else np.asarray(K)
+    # torch rounds the float64 intrinsics to fp32 where they meet the fp32 pixel grid (rays.py:28-29)
+    k4 = (C.c_float * 4)(float(np.float32(k[0][0])), float(np.float32(k[1][1])), float(np.float32(k[0][2])), float(np.float32(k[1][2])))
+    p = pose.detach().cpu().numpy() if isinstance(pose, torch.Tensor) else np.asarray(pose)
+    p = np.asarray(p, dtype=np.float32)[:3, :4]
+    return k4, (C.c_float * 12)(*p.reshape(-1).tolist())
+
+
+def make_o_d(W: int, H: int, K, pose, device, row0: int = 0, n_rows: Optional[int] = None, want_origins: bool = True):
+    n_rows = H - row0 if n_rows is None else n_rows
+    device = torch.device(device)
+    k4, p12 = _cam(K, pose)
+    d = torch.empty(n_rows, W, 3, dtype=torch.float32, device=device)
+    o = torch.empty(n_rows, W, 3, dtype=torch.float32, device=device) if want_origins else None
+    with _guard(device):
+        check(lib().mi_nerf_make_o_d(W, H, k4, p12, row0, n_rows, dev_ptr(o), dev_ptr(d), stream_ptr(device)), "mi_nerf_make_o_d")
+    return o, d
+
+
+def make_o_d_pixels(W: int, H: int, K, pose, pix: torch.Tensor):
+    device = pix.device
+    k4, p12 = _cam(K, pose)
+    n = pix.numel()
+    o = torch.empty(n, 3, dtype=torch.float32, device=device)
+    d = torch.empty(n, 3, dtype=torch.float32, device=device)
+    with _guard(device):
+        check(lib().mi_nerf_make_o_d_pixels(W, H, k4, p12, dev_ptr(pix, "pix", torch.int64, 8), n, dev_ptr(o), dev_ptr(d),
+                                            stream_ptr(device)), "mi_nerf_make_o_d_pixels")
+    return o, d
+
+
+def ndc_rays(H: int, W: int, focal: float, near: float, rays_o: torch.Tensor, rays_d: torch.Tensor):
+    device = rays_d.device
+    n = rays_d.shape[0]
+    # accept the stride-0 expanded origin view make_o_d returns (rays.py:33) without materialising it
+    def strided(t, name):
+        if t.dim() != 2 or t.shape[1] != 3 or t.dtype != torch.float32 or not t.is_cuda:
+            raise MiNerfError(f"{name} must be a [n,3] fp32 device tensor")
+        if t.stride(1) != 1 or (t.stride(0) not in (0, 3) and n > 1):
+            t = t.contiguous()
+        return t, (t.stride(0) if n > 1 else 3)
+    o, os_ = strided(rays_o, "rays_o")
+    d, ds_ = strided(rays_d, "rays_d")
+    oo = torch.empty(n, 3, dtype=torch.float32, device=device)
+    dd = torch.empty(n, 3, dtype=torch.float32, device=device)
+    with _guard(device):
+        check(lib().mi_nerf_ndc_rays(H, W, float(focal), float(near), o.data_ptr(), os_, d.data_ptr(), ds_, n, dev_ptr(oo),
+                                     dev_ptr(dd), stream_ptr(device)), "mi_nerf_ndc_rays")
+    return oo, dd
+
+
+# ------------------------------------------------------------------------------------------------
+# sampling
+# ------------------------------------------------------------------------------------------------
+def fill_uniform(seed: int, stream_id: int, ray0: int, n_rays: int, n_samples: int, device) -> torch.Tensor:
+    device = torch.device(device)
+    out = torch.empty(n_rays, n_samples, dtype=torch.float32, device=device)
+    with _guard(device):
+        check(lib().mi_nerf_fill_uniform(seed & 0xFFFFFFFF, stream_id, ray0, n_rays, n_samples, dev_ptr(out), stream_ptr(device)),
+              "mi_nerf_fill_uniform")
+    return out
+
+
+def stratified_z(near: float, far: float, t_rand: torch.Tensor) -> torch.Tensor:
+    n, S = t_rand.shape
+    z = torch.empty_like(t_rand)
+    with _guard(t_rand.device):
+        check(lib().mi_nerf_stratified_z(n, S, float(near), float(far), dev_ptr(t_rand, "t_rand"), dev_ptr(z),
+                                         stream_ptr(t_rand.device)), "mi_nerf_stratified_z")
+    return z
+
+
+def sample_pdf(bins: torch.Tensor, weights: torch.Tensor, N: int, det: bool, u: Optional[torch.Tensor]) -> torch.Tensor:
+    n, B = bins.shape
+    if tuple(weights.shape) != (n, B - 1):
+        raise MiNerfError(f"weights must be [n, B-1] = {(n, B - 1)}, got {tuple(weights.shape)}")
+    if not det and (u is None or tuple(u.shape) != (n, N)):
+        raise MiNerfError("u [n, N] is required unless det")
+    out = torch.empty(n, N, dtype=torch.float32, device=bins.device)
+    with _guard(bins.device):
+        check(lib().mi_nerf_sample_pdf(dev_ptr(bins, "bins"), dev_ptr(weights, "weights"), n, B, N, int(det),
+                                       None if det else dev_ptr(u, "u"), dev_ptr(out), stream_ptr(bins.device)), "mi_nerf_sample_pdf")
+    return out
+
+
+def fine_z(z_c: torch.Tensor, weights_c: torch.Tensor, Nf: int, det: bool, u: Optional[torch.Tensor], want_samples: bool = False):
+    n, Sc = z_c.shape
+    if tuple(weights_c.shape) != (n, Sc):
+        raise MiNerfError("weights_c must match z_c")
+    if not det and (u is None or tuple(u.shape) != (n, Nf)):
+        raise MiNerfError("u [n, Nf] is required unless det")
+    z_f = torch.empty(n, Sc + Nf, dtype=torch.float32, device=z_c.device)
+    zs = torch.empty(n, Nf, dtype=torch.float32, device=z_c.device) if want_samples else None
+    with _guard(z_c.device):
+        check(lib().mi_nerf_fine_z(dev_ptr(z_c, "z_c"), dev_ptr(weights_c, "weights_c"), n, Sc, Nf, int(det),
+                                   None if det else dev_ptr(u, "u"), dev_ptr(z_f), dev_ptr(zs), stream_ptr(z_c.device)), "mi_nerf_fine_z")
+    return (z_f, zs) if want_samples else z_f
+
+
+# ------------------------------------------------------------------------------------------------
+# encoding, network, compositing
+# ------------------------------------------------------------------------------------------------
+def embed(rays: torch.Tensor, z: torch.Tensor, L_x: int, L_d: int) -> torch.Tensor:
+    n, S = z.shape
+    out = torch.empty(n * S, 6 + 6 * L_x + 6 * L_d, dtype=torch.float32, device=z.device)
+    with _guard(z.device):
+        check(lib().mi_nerf_embed(dev_ptr(rays, "rays"), dev_ptr(z, "z"), n, S, L_x, L_d, dev_ptr(out), stream_ptr(z.device)), "mi_nerf_embed")
+    return out
+
+
+def posenc(x: torch.Tensor, Lf: int) -> torch.Tensor:
+    n = x.shape[0]
+    out = torch.empty(n, 3 + 6 * Lf, dtype=torch.float32, device=x.device)
+    with _guard(x.device):
+        check(lib().mi_nerf_posenc(dev_ptr(x, "x"), n, Lf, dev_ptr(out), stream_ptr(x.device)), "mi_nerf_posenc")
+    return out
+
+
+def mlp_embedded(net: Net, packed: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    n = x.shape[0]
+    if x.dim() != 2 or x.shape[1] != 6 + 6 * net.L_x + 6 * net.L_d:
+        raise MiNerfError(f"x must be [n, {6 + 6 * net.L_x + 6 * net.L_d}], got {tuple(x.shape)}")
+    out = torch.empty(n, 4, dtype=torch.float32, device=x.device)
+    with _guard(x.device):
+        check(lib().mi_nerf_mlp_embedded(C.byref(net), dev_ptr(packed, "packed", torch.uint8, 16), dev_ptr(x, "x"), n, dev_ptr(out, "out", align=16),
+                                         stream_ptr(x.device)), "mi_nerf_mlp_embedded")
+    return out
+
+
+def mlp_rays(net: Net, packed: torch.Tensor, rays: torch.Tensor, z: torch.Tensor, bf16: bool = False) -> torch.Tensor:
+    n, S = z.shape
+    if tuple(rays.shape) != (n, 6):
+        raise MiNerfError(f"rays must be [n,6], got {tuple(rays.shape)}")
+    raw = torch.empty(n, S, 4, dtype=torch.float32, device=z.device)
+    fn = lib().mi_nerf_mlp_rays_bf16 if bf16 else lib().mi_nerf_mlp_rays
+    with _guard(z.device):
+        check(fn(C.byref(net), dev_ptr(packed, "packed", torch.uint8, 16), dev_ptr(rays, "rays"), dev_ptr(z, "z"), n, S,
+                 dev_ptr(raw, "raw", align=16), stream_ptr(z.device)), "mi_nerf_mlp_rays")
+    return raw
+
+
+def composite(raw: torch.Tensor, z: torch.Tensor, rays_or_d: torch.Tensor, want_all: bool = True):
+    n, S = z.shape
+    if tuple(raw.shape) != (n, S, 4):
+        raise MiNerfError(f"raw must be [n,S,4] = {(n, S, 4)}, got {tuple(raw.shape)}")
+    stride = rays_or_d.shape[-1]
+    if tuple(rays_or_d.shape) != (n, stride) or stride not in (3, 6):
+        raise MiNerfError("rays must be [n,6] or rays_d [n,3]")
+    dev = z.device
+    rgb = torch.empty(n, 3, dtype=torch.float32, device=dev)
+    disp = torch.empty(n, dtype=torch.float32, device=dev)
+    acc = torch.empty(n, dtype=torch.float32, device=dev) if want_all else None
+    wts = torch.empty(n, S, dtype=torch.float32, device=dev) if want_all else None
+    depth = torch.empty(n, dtype=torch.float32, device=dev) if want_all else None
+    with _guard(dev):
+        check(lib().mi_nerf_composite(dev_ptr(raw, "raw", align=16), dev_ptr(z, "z"), dev_ptr(rays_or_d, "rays"), stride, n, S, dev_ptr(rgb),
+                                      dev_ptr(disp), dev_ptr(acc), dev_ptr(wts), dev_ptr(depth), stream_ptr(dev)), "mi_nerf_composite")
+    return rgb, disp, acc, wts, depth
+
+
+# ------------------------------------------------------------------------------------------------
+# fused render
+# ------------------------------------------------------------------------------------------------
+def render_cfg(near: float, far: float, Sc: int, Nf: int, det: bool, bf16: bool = False) -> RenderCfg:
+    return RenderCfg(float(near), float(far), int(Sc), int(Nf), int(bool(det)), int(bool(bf16)))
+
+
+def workspace_layout(cfg: RenderCfg, n: int) -> WorkspaceLayout:
+    wl = WorkspaceLayout()
+    check(lib().mi_nerf_render_workspace_layout(C.byref(cfg), n, C.byref(wl)), "mi_nerf_render_workspace_layout")
+    return wl
+
+
+def render_rays(net: Net, packed_c: torch.Tensor, packed_f: Optional[torch.Tensor], cfg: RenderCfg, rays: torch.Tensor,
+                t_rand: torch.Tensor, u: Optional[torch.Tensor], workspace: Optional[torch.Tensor] = None,
+                out: Optional[Sequence[torch.Tensor]] = None):
+    """One mi_nerf_render_rays call.  Returns (rgb_c, disp_c, rgb_f|None, disp_f|None, workspace)."""
+    n = rays.shape[0]
+    dev = rays.device
+    if tuple(rays.shape) != (n, 6) or tuple(t_rand.shape) != (n, cfg.Sc):
+        raise MiNerfError(f"rays [n,6] / t_rand [n,{cfg.Sc}] expected, got {tuple(rays.shape)} / {tuple(t_rand.shape)}")
+    if cfg.Nf > 0 and not cfg.det and (u is None or tuple(u.shape) != (n, cfg.Nf)):
+        raise MiNerfError(f"u [n,{cfg.Nf}] expected")
+    wl = workspace_layout(cfg, n)
+    if workspace is None or workspace.numel() < wl.total:
+        workspace = torch.empty(max(wl.total, 256), dtype=torch.uint8, device=dev)
+    if out is None:
+        rgb_c = torch.empty(n, 3, dtype=torch.float32, device=dev)
+        disp_c = torch.empty(n, dtype=torch.float32, device=dev)
+        rgb_f = torch.empty(n, 3, dtype=torch.float32, device=dev) if cfg.Nf > 0 else None
+        disp_f = torch.empty(n, dtype=torch.float32, device=dev) if cfg.Nf > 0 else None
+    else:
+        rgb_c, disp_c, rgb_f, disp_f = out
+    with _guard(dev):
+        check(lib().mi_nerf_render_rays(C.byref(net), dev_ptr(packed_c, "packed_coarse", torch.uint8, 16),
+                                        dev_ptr(packed_f, "packed_fine", torch.uint8, 16), C.byref(cfg), dev_ptr(rays, "rays"), n,
+                                        dev_ptr(t_rand, "t_rand"), dev_ptr(u, "u") if (cfg.Nf > 0 and not cfg.det) else None,
+                                        dev_ptr(workspace, "workspace", torch.uint8, 256), workspace.numel(), dev_ptr(rgb_c), dev_ptr(disp_c),
+                                        dev_ptr(rgb_f), dev_ptr(disp_f), stream_ptr(dev)), "mi_nerf_render_rays")
+    return rgb_c, disp_c, rgb_f, disp_f, workspace
+
+
+def workspace_views(cfg: RenderCfg, n: int, workspace: torch.Tensor) -> Dict[str, torch.Tensor]:
+    """Typed views of the intermediates inside a render workspace (staged parity checks)."""
+    wl = workspace_layout(cfg, n)
+    Sc, St = cfg.Sc, cfg.Sc + cfg.Nf
+    def view(off, shape):
+        cnt = int(np.prod(shape))
+        return workspace[off:off + cnt * 4].view(torch.float32).view(*shape)
+    v = {"z_c": view(wl.z_c, (n, Sc)), "raw_c": view(wl.raw_c, (n, Sc, 4)), "weights_c": view(wl.weights_c, (n, Sc))}
+    if cfg.Nf > 0:
+        v["z_f"] = view(wl.z_f, (n, St))
+        v["raw_f"] = view(wl.raw_f, (n, St, 4))
+    return v
+
+
+def time_mlp_rays(net: Net, packed: torch.Tensor, rays: torch.Tensor, z: torch.Tensor, raw: torch.Tensor, iters: int, bf16: bool = False) -> float:
+    """Average device milliseconds per fused-MLP launch, from hipEvents on the launch stream."""
+    n, S = z.shape
+    ms = C.c_float(0.0)
+    with _guard(z.device):
+        check(lib().mi_nerf_time_mlp_rays(C.byref(net), dev_ptr(packed, "packed", torch.uint8, 16), dev_ptr(rays, "rays"), dev_ptr(z, "z"), n, S,
+                                          dev_ptr(raw, "raw", align=16), iters, int(bf16), C.byref(ms), stream_ptr(z.device)), "mi_nerf_time_mlp_rays")
+    return float(ms.value)
+
+
+def selftest_mfma(device) -> None:
+    device = torch.device(device)
+    with _guard(device):
+        check(lib().mi_nerf_selftest_mfma(stream_ptr(device)), "mi_nerf_selftest_mfma")

@@ -1,0 +1,112 @@
+"""Weight ingest: reference checkpoint layout -> device-resident packed blobs.
+
+The reference keeps its parameters in an ``nn.Module`` whose ``state_dict`` has the keys
+``model_{coarse,fine}.linear_x.{i}.{weight,bias}``, ``linear_d``, ``linear_feat``, ``linear_density``,
+``linear_color`` (model/NeRF.py:24-30,58-59; saved at train.py:105-114, loaded at test.py:20-21).
+``PackedNeRF`` accepts such a state dict (numpy or torch), infers (D, W, skip, L_x, L_d) from the
+shapes, packs both networks into the kernels' streaming layout and keeps the blobs on the device.
+"""
+from __future__ import annotations
+
+import weakref
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import ops
+from ._lib import MiNerfError, Net
+
+
+def infer_net(sd: Dict[str, "np.ndarray | torch.Tensor"], prefix: str = "model_coarse.") -> Net:
+    """(D, W, skip, L_x, L_d) from parameter shapes (the construction rule of model/NeRF.py:24-30)."""
+    def shape(k):
+        return tuple(sd[prefix + k].shape)
+    D = 0
+    while f"{prefix}linear_x.{D}.weight" in sd:
+        D += 1
+    if D == 0:
+        raise MiNerfError(f"no {prefix}linear_x.0.weight in state dict")
+    W, in_x = shape("linear_x.0.weight")
+    skip = -1
+    for l in range(1, D):
+        fan_in = shape(f"linear_x.{l}.weight")[1]
+        if fan_in == W + in_x:
+            if skip != -1:
+                raise MiNerfError("more than one skip connection is not supported")
+            skip = l - 1
+        elif fan_in != W:
+            raise MiNerfError(f"unexpected fan-in {fan_in} at trunk layer {l}")
+    in_d = shape("linear_d.weight")[1] - W
+    if (in_x - 3) % 6 or (in_d - 3) % 6:
+        raise MiNerfError(f"input widths {in_x}/{in_d} are not 3+6L")
+    return ops.make_net(D, W, skip, (in_x - 3) // 6, (in_d - 3) // 6)
+
+
+class PackedNeRF:
+    """Both networks of a NeRF, packed and resident on one device."""
+
+    def __init__(self, net: Net, coarse: torch.Tensor, fine: torch.Tensor):
+        self.net, self.coarse, self.fine = net, coarse, fine
+        self._bf16: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
+        self._sd = None
+
+    @property
+    def device(self) -> torch.device:
+        return self.coarse.device
+
+    @classmethod
+    def from_state_dict(cls, sd, device, keep_state: bool = True) -> "PackedNeRF":
+        net = infer_net(sd)
+        fine_net = infer_net(sd, "model_fine.")
+        if tuple(getattr(net, f) for f, _ in Net._fields_) != tuple(getattr(fine_net, f) for f, _ in Net._fields_):
+            raise MiNerfError("coarse and fine networks differ in shape")
+        c = ops.pack_module(sd, "model_coarse.", net).to(device)
+        f = ops.pack_module(sd, "model_fine.", net).to(device)
+        self = cls(net, c, f)
+        if keep_state:
+            self._sd = {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in sd.items()
+                        if k.startswith("model_")}
+        return self
+
+    def bf16(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        """bf16-stream blobs for the bf16 MFMA variant (packed lazily)."""
+        if self._bf16 is None:
+            if self._sd is None:
+                raise MiNerfError("bf16 packing needs the state dict (keep_state=True)")
+            self._bf16 = (ops.pack_module(self._sd, "model_coarse.", self.net, bf16=True).to(self.device),
+                          ops.pack_module(self._sd, "model_fine.", self.net, bf16=True).to(self.device))
+        return self._bf16
+
+    def blob(self, is_fine: bool) -> torch.Tensor:
+        return self.fine if is_fine else self.coarse
+
+
+# ---------------------------------------------------------------------------------------------------
+# cache for nn.Module models (ours or the reference's): repack only when a parameter changed
+# ---------------------------------------------------------------------------------------------------
+_cache: "weakref.WeakKeyDictionary[torch.nn.Module, Tuple[tuple, PackedNeRF]]" = weakref.WeakKeyDictionary()
+
+
+def _fingerprint(model: torch.nn.Module) -> tuple:
+    return tuple((p.data_ptr(), p._version, str(p.device)) for p in model.parameters())
+
+
+def packed_for(model, device=None) -> PackedNeRF:
+    """PackedNeRF for ``model``: a PackedNeRF passes through; an nn.Module with the reference's
+    ``model_coarse`` / ``model_fine`` layout is packed once and cached until its parameters change."""
+    if isinstance(model, PackedNeRF):
+        return model
+    if not isinstance(model, torch.nn.Module) or not hasattr(model, "model_coarse") or not hasattr(model, "model_fine"):
+        raise MiNerfError("model must be a PackedNeRF or an nn.Module with model_coarse / model_fine (model/NeRF.py:58-59)")
+    fp = _fingerprint(model)
+    hit = _cache.get(model)
+    if hit is not None and hit[0] == fp and (device is None or hit[1].device == torch.device(device)):
+        return hit[1]
+    if device is None:
+        device = next(model.parameters()).device
+    if torch.device(device).type != "cuda":
+        raise MiNerfError(f"model lives on {device}: the MI355X path needs a HIP device (no CPU fallback)")
+    packed = PackedNeRF.from_state_dict(model.state_dict(), device)
+    _cache[model] = (fp, packed)
+    return packed
