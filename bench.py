@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""Benchmark of the NeRF volume-rendering hot path on MI355X (driver contract: one JSON line on rank 0).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json): rays/sec on a 4096-ray batch with 64 coarse + 128 fine samples through the 8x256
+coarse/fine MLPs, fp32 -- BASELINE config #2, "lego coarse+fine 4096 rays, 64+128 samples, 8x256 MLP,
+1xMI355X fp32".  One step = one full render_rays pass (stratified sampling -> coarse MLP -> composite ->
+inverse-CDF resampling + merge -> fine MLP over all 192 depths -> composite) over one 4096-ray batch whose
+rays are resident in HBM.  With N GPUs every rank renders its own 4096-ray batch (weak scaling: rays are
+independent, no data-path collective); value = N * 4096 * K / max-over-ranks time.
+
+Also reported on the same line: the 800x800 frame time (rows sharded over the ranks, one RCCL all-gather of
+the output tiles), `roofline` for the dominant kernel (the fine-network fused MLP launch, hipEvent-timed on
+its launch stream) and `cpu_baseline` (the CPU oracle timed on the host cores; rank 0, N=1 only).
+
+Synthetic inputs: lego camera geometry, pose_spherical(0,-30,4), 4096 pixels from
+RandomState(0), Xavier(seed 0) weights with the density head x20, counter-based jitter seed 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# algorithmic work: 2 x MACs of the Linear layers only
+FLOP_PER_POINT = 2 * 593408              # 8x256 network, model/NeRF.py:24-30
+N_RAYS, SC, NF = 4096, 64, 128
+POINTS_PER_RAY = SC + (SC + NF)          # 64 coarse + 192 fine network evaluations
+FLOP_PER_RAY = FLOP_PER_POINT * POINTS_PER_RAY          # 303,824,896
+PEAK_F32_MFMA_TFLOPS = 157.3             # MI355X_MICROARCH.md: 256 CU x 256 FLOP/clk x 2.4 GHz
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--frames", type=int, default=2, help="timed 800x800 frames (0 disables the frame metric)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--bf16", action="store_true", help="bf16 MFMA variant (BASELINE config #5)")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from nerf_pytorch_paeng_amd import dist as mdist
+    from nerf_pytorch_paeng_amd import nerf_process as NP
+    from nerf_pytorch_paeng_amd import ops, synthetic, weights
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    # ---- inputs (resident in HBM before any timed region) ----------------------------------------------
+    sd = synthetic.make_state_dict(0, 8, 256)
+    packed = weights.PackedNeRF.from_state_dict(sd, dev)
+    K, H, W = synthetic.lego_camera()
+    pose = synthetic.pose_spherical(0.0, -30.0, 4.0)
+    pix_all = synthetic.pixel_batch(H, W, N_RAYS * world, 0)                # each rank gets its own 4096 pixels
+    pix = torch.from_numpy(pix_all[rank * N_RAYS:(rank + 1) * N_RAYS]).to(dev)
+    o, d = ops.make_o_d_pixels(W, H, K, pose, pix)
+    rays = torch.cat([o, d], -1).contiguous()
+    opts = SimpleNamespace(near=2.0, far=6.0, N_samples_c=SC, N_samples_f=NF, perturb=1.0, chunk_rays=N_RAYS,
+                           chunk_pts=524288, data_type="blender", gpu_ids=list(range(world)), rank=rank)
+    cfg = ops.render_cfg(opts.near, opts.far, SC, NF, False, args.bf16)
+    t_rand = ops.fill_uniform(0, 0, rank * N_RAYS, N_RAYS, SC, dev)
+    u = ops.fill_uniform(0, 1, rank * N_RAYS, N_RAYS, NF, dev)
+    blobs = packed.bf16() if args.bf16 else (packed.coarse, packed.fine)
+    out_bufs = (torch.empty(N_RAYS, 3, device=dev), torch.empty(N_RAYS, device=dev),
+                torch.empty(N_RAYS, 3, device=dev), torch.empty(N_RAYS, device=dev))
+    ws = torch.empty(ops.workspace_layout(cfg, N_RAYS).total, dtype=torch.uint8, device=dev)
+
+    def step():
+        ops.render_rays(packed.net, blobs[0], blobs[1], cfg, rays, t_rand, u, workspace=ws, out=out_bufs)
+
+    # ---- rays/sec on the 4096-ray batch ------------------------------------------------------------------
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    rays_per_s = world * N_RAYS * args.steps / elapsed
+    ms_per_step = 1e3 * elapsed / args.steps
+    assert torch.isfinite(out_bufs[2]).all()
+
+    # ---- roofline of the dominant kernel: the fine-network fused MLP launch ---------------------------------
+    views = ops.workspace_views(cfg, N_RAYS, ws)
+    z_f = views["z_f"].clone()
+    raw_f = torch.empty(N_RAYS, SC + NF, 4, device=dev)
+    iters = max(5, min(args.steps, 50))
+    ops.time_mlp_rays(packed.net, blobs[1], rays, z_f, raw_f, 2, args.bf16)
+    k_ms = ops.time_mlp_rays(packed.net, blobs[1], rays, z_f, raw_f, iters, args.bf16)
+    k_flop = N_RAYS * (SC + NF) * FLOP_PER_POINT                             # algorithmic FLOP per launch
+    achieved = k_flop / (k_ms * 1e-3) / 1e12
+    roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                "kernel": "mlp_fp32_kernel<256,0,10,4> (fine net, 786432 points/launch)", "kernel_ms": round(k_ms, 4),
+                "flop_per_launch": k_flop}
+    if args.bf16:
+        roofline["kernel"] = "mlp_bf16_kernel (fine net, 786432 points/launch)"
+        roofline["frac_of_bf16_peak"] = round(achieved / 2500.0, 4)
+
+    # ---- 800x800 frame, rows sharded over the ranks, one all-gather of the tiles ----------------------------
+    frame_ms = None
+    if args.frames > 0:
+        mdist.render_frame(H, W, K, pose, packed, opts, seed=0, bf16=args.bf16)            # warm-up frame
+        torch.cuda.synchronize(dev)
+        barrier()
+        t0 = time.perf_counter()
+        for f in range(args.frames):
+            rgb, disp = mdist.render_frame(H, W, K, synthetic.pose_spherical(3.0 * (f + 1), -30.0, 4.0), packed, opts, seed=0, bf16=args.bf16)
+        torch.cuda.synchronize(dev)
+        barrier()
+        ft = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([ft], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            ft = float(tmax.item())
+        frame_ms = 1e3 * ft / args.frames
+        assert rgb.shape == (H, W, 3) and torch.isfinite(rgb).all()
+
+    # ---- CPU baseline: the oracle (a port: the reference cannot leave the build container) -------------------
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import restate as R
+        # the GPU box gives one GPU's job a 16-core share of a many-core host: do not oversubscribe
+        n_thr = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
+        torch.set_num_threads(n_thr)
+        rc, tc, uc = rays.cpu(), t_rand.cpu(), u.cpu()
+        pcfg = R.PathConfig()
+        with torch.no_grad():
+            R.render_rays(rc[:256], sd, pcfg, tc[:256], uc[:256])                            # warm-up
+            reps, spent, n_cpu = [], 0.0, 1024
+            while spent < 12.0 and len(reps) < 3:
+                t0 = time.perf_counter()
+                R.render_rays(rc[:n_cpu], sd, pcfg, tc[:n_cpu], uc[:n_cpu])
+                dt = time.perf_counter() - t0
+                reps.append(dt)
+                spent += dt
+        cpu = {"value": round(n_cpu / float(np.median(reps)), 1), "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+               "sample": f"oracle/restate.py render_rays (torch CPU fp32) on the first {n_cpu} rays of the same 4096-ray batch, "
+                         f"median of {len(reps)} reps"}
+
+    if rank == 0:
+        line = {
+            "metric": "rays/sec (4096-ray batch, 64c+128f samples) + 800x800 frame render ms",
+            "value": round(rays_per_s, 1), "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if args.bf16 else "f32", "data": "synthetic",
+            "config": {"workload": "lego coarse+fine 4096 rays per GPU, 64+128 samples, 8x256 MLP (BASELINE config #2)",
+                       "rays_per_gpu": N_RAYS, "samples": [SC, NF], "net": "8x256, skip 4, L_x 10, L_d 4",
+                       "parallelism": f"rays sharded over {world} GPU(s), no data-path collective"},
+            "frame_ms_800x800": None if frame_ms is None else round(frame_ms, 2),
+            "frac_of_f32_mfma_roofline_end_to_end": round(rays_per_s / world * FLOP_PER_RAY / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+            "roofline": roofline,
+        }
+        if cpu is not None:
+            line["cpu_baseline"] = cpu
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

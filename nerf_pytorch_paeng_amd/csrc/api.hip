@@ -178,10 +178,10 @@ int mi_nerf_render_rays(const mi_nerf_net* net, const void* packed_c, const void
     hipStream_t st = (hipStream_t)stream;
     mi_nerf_workspace_layout L;
     if (int rc = workspace_layout(cfg, n, &L)) return rc;
+    if (n == 0) return MI_NERF_OK;
     MN_CHECK_ARG(ws_bytes >= L.total, "workspace too small: %zu < %zu", ws_bytes, L.total);
     MN_CHECK_ARG(rays && t_rand && rgb_c && disp_c && packed_c && (ws || L.total == 0), "NULL pointer");
     MN_CHECK_ARG(cfg->Nf == 0 || (packed_f && rgb_f && disp_f && (cfg->det || u)), "fine pass needs packed_fine, outputs and u");
-    if (n == 0) return MI_NERF_OK;
     char* w = (char*)ws;
     float* z_c = (float*)(w + L.z_c);
     float* raw_c = (float*)(w + L.raw_c);

@@ -396,9 +396,9 @@ static void fill_common(MlpArgs& a, const mi_nerf_net* net, const void* packed_d
 int mlp_rays_fp32(const mi_nerf_net* net, const void* packed_dev, const float* rays_dev, const float* z_dev,
                   int64_t n_rays, int S, float* raw_dev, hipStream_t st) {
     if (int rc = check_net(net)) return rc;
-    MN_CHECK_ARG(packed_dev && rays_dev && z_dev && raw_dev, "NULL device pointer");
     MN_CHECK_ARG(n_rays >= 0 && S >= 1, "bad sizes n_rays=%lld S=%d", (long long)n_rays, S);
     if (n_rays == 0) return MI_NERF_OK;
+    MN_CHECK_ARG(packed_dev && rays_dev && z_dev && raw_dev, "NULL device pointer");
     MlpArgs a{};
     fill_common(a, net, packed_dev, false);
     a.rays = rays_dev; a.z = z_dev; a.out = raw_dev; a.S = S; a.tpr = (S + 31) / 32;
@@ -409,9 +409,9 @@ int mlp_rays_fp32(const mi_nerf_net* net, const void* packed_dev, const float* r
 int mlp_embedded_fp32(const mi_nerf_net* net, const void* packed_dev, const float* x_dev, int64_t n, float* out_dev,
                       hipStream_t st) {
     if (int rc = check_net(net)) return rc;
-    MN_CHECK_ARG(packed_dev && x_dev && out_dev, "NULL device pointer");
     MN_CHECK_ARG(n >= 0, "bad n=%lld", (long long)n);
     if (n == 0) return MI_NERF_OK;
+    MN_CHECK_ARG(packed_dev && x_dev && out_dev, "NULL device pointer");
     MlpArgs a{};
     fill_common(a, net, packed_dev, true);
     a.x = x_dev; a.out = out_dev; a.n_pts = n;

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void fill_uniform_kernel(uint32_t seed, uint32
 
 // torch.linspace(0,1,S)[i] in fp32 (symmetric fill: ATen RangeFactories) and z = near*(1-t) + far*t
 __device__ __forceinline__ float strat_edge(int i, int S, float step, float near_, float far_) {
-    const float t = (i < S / 2) ? step * (float)i : 1.0f - step * (float)(S - 1 - i);
+    const float t = (S == 1) ? 0.0f : (i < S / 2) ? step * (float)i : 1.0f - step * (float)(S - 1 - i);   // steps=1 -> [start]
     return near_ * (1.0f - t) + far_ * t;               // nerf_process.py:53
 }
 
@@ -226,7 +226,8 @@ __global__ __launch_bounds__(256) void composite_kernel(const float* __restrict_
         dist = dist * dnorm;                                               // :101
         const float sig = __builtin_fmaxf(v[3], 0.0f);                     // relu, :91
         float a = 1.0f - expf(-sig * dist);                                // :92
-        if (!in) a = 0.0f;
+        // S == 1: the reference's `dists[..., :1]` slice of an empty tensor leaves NO samples at all (white, acc 0)
+        if (!in || S == 1) a = 0.0f;
         alpha[c] = a;
         cr[c] = 1.0f / (1.0f + expf(-v[0]));                               // sigmoid, :104
         cg[c] = 1.0f / (1.0f + expf(-v[1]));
@@ -395,8 +396,9 @@ int stage_make_o_d_pixels(int W, int H, const float k4[4], const float pose12[12
 
 int stage_ndc(int H, int W, float focal, float near_, const float* o_in, int64_t os, const float* d_in, int64_t ds, int64_t n,
               float* o_out, float* d_out, hipStream_t st) {
-    MN_CHECK_ARG(H > 0 && W > 0 && n >= 0 && o_in && d_in && o_out && d_out, "bad arguments");
+    MN_CHECK_ARG(H > 0 && W > 0 && n >= 0, "bad sizes");
     if (n == 0) return MI_NERF_OK;
+    MN_CHECK_ARG(o_in && d_in && o_out && d_out, "NULL pointer");
     // python-float (double) scale factors, rounded once to fp32 where they meet the tensors (nerf_process.py:15-23)
     const float sx = (float)(-1.0 / ((double)W / (2.0 * (double)focal)));
     const float sy = (float)(-1.0 / ((double)H / (2.0 * (double)focal)));
@@ -417,9 +419,10 @@ int stage_fill_uniform(uint32_t seed, uint32_t stream_id, int64_t ray0, int64_t 
 }
 
 int stage_stratified(int64_t n_rays, int S, float near_, float far_, const float* t_rand, float* z, hipStream_t st) {
-    MN_CHECK_ARG(n_rays >= 0 && S >= 1 && t_rand && z, "bad arguments");
+    MN_CHECK_ARG(n_rays >= 0 && S >= 1, "bad sizes");
     const long long total = (long long)n_rays * S;
     if (total == 0) return MI_NERF_OK;
+    MN_CHECK_ARG(t_rand && z, "NULL pointer");
     const float step = S > 1 ? 1.0f / (float)(S - 1) : 0.0f;
     hipLaunchKernelGGL(stratified_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, st, total, S, near_, far_, step, t_rand, z);
     MN_LAUNCH_CHECK("stratified_kernel");
@@ -427,19 +430,21 @@ int stage_stratified(int64_t n_rays, int S, float near_, float far_, const float
 }
 
 int stage_embed(const float* rays, const float* z, int64_t n_rays, int S, int L_x, int L_d, float* out, hipStream_t st) {
-    MN_CHECK_ARG(n_rays >= 0 && S >= 1 && L_x >= 0 && L_x <= 20 && L_d >= 0 && L_d <= 20 && rays && z && out, "bad arguments");
+    MN_CHECK_ARG(n_rays >= 0 && S >= 1 && L_x >= 0 && L_x <= 20 && L_d >= 0 && L_d <= 20, "bad sizes");
     const long long n_pts = (long long)n_rays * S;
     const long long total = n_pts * (6 + 6 * L_x + 6 * L_d);
     if (total == 0) return MI_NERF_OK;
+    MN_CHECK_ARG(rays && z && out, "NULL pointer");
     hipLaunchKernelGGL(embed_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, st, rays, z, n_pts, S, L_x, L_d, out);
     MN_LAUNCH_CHECK("embed_kernel");
     return MI_NERF_OK;
 }
 
 int stage_posenc(const float* x, int64_t n, int L, float* out, hipStream_t st) {
-    MN_CHECK_ARG(n >= 0 && L >= 0 && L <= 20 && x && out, "bad arguments");
+    MN_CHECK_ARG(n >= 0 && L >= 0 && L <= 20, "bad sizes");
     const long long total = (long long)n * (3 + 6 * L);
     if (total == 0) return MI_NERF_OK;
+    MN_CHECK_ARG(x && out, "NULL pointer");
     hipLaunchKernelGGL(posenc_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, st, x, (long long)n, L, out);
     MN_LAUNCH_CHECK("posenc_kernel");
     return MI_NERF_OK;
@@ -447,9 +452,10 @@ int stage_posenc(const float* x, int64_t n, int L, float* out, hipStream_t st) {
 
 int stage_composite(const float* raw, const float* z, const float* rays, int ray_stride, int64_t n, int S, float* rgb, float* disp,
                     float* acc, float* weights, float* depth, hipStream_t st) {
-    MN_CHECK_ARG(n >= 0 && S >= 1 && S <= 1024 && raw && z && rays && rgb && disp, "bad arguments (S=%d)", S);
+    MN_CHECK_ARG(n >= 0 && S >= 1 && S <= 1024, "bad sizes (n=%lld S=%d)", (long long)n, S);
     MN_CHECK_ARG(ray_stride == 3 || ray_stride == 6, "ray_stride must be 3 or 6");
     if (n == 0) return MI_NERF_OK;
+    MN_CHECK_ARG(raw && z && rays && rgb && disp, "NULL pointer");
     const dim3 grid(blocks_for(n, 4)), block(256);
     const int C = (S + 63) / 64;
 #define MN_COMP(CC) hipLaunchKernelGGL(composite_kernel<CC>, grid, block, 0, st, raw, z, rays, ray_stride, (long long)n, S, rgb, disp, acc, weights, depth)
@@ -462,8 +468,9 @@ int stage_composite(const float* raw, const float* z, const float* rays, int ray
 
 int stage_sample_pdf(const float* bins, const float* weights, int64_t n, int B, int N, int det, const float* u, float* out,
                      hipStream_t st) {
-    MN_CHECK_ARG(n >= 0 && B >= 2 && B <= 4096 && N >= 1 && bins && weights && out && (det || u), "bad arguments (B=%d N=%d)", B, N);
+    MN_CHECK_ARG(n >= 0 && B >= 2 && B <= 4096 && N >= 1, "bad sizes (B=%d N=%d)", B, N);
     if (n == 0) return MI_NERF_OK;
+    MN_CHECK_ARG(bins && weights && out && (det || u), "NULL pointer");
     hipLaunchKernelGGL(sample_pdf_kernel, dim3(blocks_for(n, 4)), dim3(256), (size_t)4 * 2 * B * sizeof(float), st, bins, weights,
                        (long long)n, B, N, det, u, out);
     MN_LAUNCH_CHECK("sample_pdf_kernel");
@@ -472,8 +479,9 @@ int stage_sample_pdf(const float* bins, const float* weights, int64_t n, int B, 
 
 int stage_fine_z(const float* z_c, const float* w_c, int64_t n, int Sc, int Nf, int det, const float* u, float* z_f, float* z_samp,
                  hipStream_t st) {
-    MN_CHECK_ARG(n >= 0 && Sc >= 3 && Nf >= 1 && Sc + Nf <= 4096 && z_c && w_c && z_f && (det || u), "bad arguments (Sc=%d Nf=%d)", Sc, Nf);
+    MN_CHECK_ARG(n >= 0 && Sc >= 3 && Nf >= 1 && Sc + Nf <= 4096, "bad sizes (Sc=%d Nf=%d)", Sc, Nf);
     if (n == 0) return MI_NERF_OK;
+    MN_CHECK_ARG(z_c && w_c && z_f && (det || u), "NULL pointer");
     const size_t lds = (size_t)4 * (2 * (Sc - 1) + Sc + Nf) * sizeof(float);
     hipLaunchKernelGGL(fine_z_kernel, dim3(blocks_for(n, 4)), dim3(256), lds, st, z_c, w_c, (long long)n, Sc, Nf, det, u, z_f, z_samp);
     MN_LAUNCH_CHECK("fine_z_kernel");
