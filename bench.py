@@ -128,8 +128,14 @@ def main():
     k_ms = ops.time_mlp_rays(packed.net, blobs[1], rays, z_f, raw_f, iters, args.bf16)
     k_flop = N_RAYS * (SC + NF) * FLOP_PER_POINT                             # algorithmic FLOP per launch
     achieved = k_flop / (k_ms * 1e-3) / 1e12
+    traffic = None                     # HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/README.md)
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            traffic = None if args.bf16 else json.load(f)["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                 "kernel": "mlp_fp32_kernel<256,0,10,4> (fine net, 786432 points/launch)", "kernel_ms": round(k_ms, 4),
                 "flop_per_launch": k_flop}
     if args.bf16:
