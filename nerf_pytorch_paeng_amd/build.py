@@ -20,7 +20,9 @@ INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libmi_nerf.so")
 SOURCES = ["api.hip", "stages.hip", "mlp_fp32.hip", "mlp_bf16.hip", "pack.cpp"]
 ARCH = "gfx950"
-FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
+         # the MLP kernel's register-resident design needs its k-loops FULLY unrolled (static register indices)
+         "-mllvm", "-pragma-unroll-threshold=1000000"]
 
 
 def _hipcc() -> str:
@@ -35,15 +37,15 @@ def _deps_mtime() -> float:
     return max(os.path.getmtime(h) for h in hs)
 
 
-def _compile(src: str, force: bool) -> str:
-    bdir = os.path.join(CSRC, "build")
+def _compile(src: str, force: bool, extra=(), tag: str = "") -> str:
+    bdir = os.path.join(CSRC, "build" + tag)
     os.makedirs(bdir, exist_ok=True)
     obj = os.path.join(bdir, src + ".o")
     spath = os.path.join(CSRC, src)
     if (not force and os.path.exists(obj) and os.path.getmtime(obj) >= os.path.getmtime(spath)
             and os.path.getmtime(obj) >= _deps_mtime()):
         return obj
-    cmd = [_hipcc(), *FLAGS, "-x", "hip", "-c", spath, "-o", obj]
+    cmd = [_hipcc(), *FLAGS, *extra, "-x", "hip", "-c", spath, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
@@ -65,5 +67,18 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+def build_diag_library() -> str:
+    """Diagnostic variant (-DMN_DIAG: s_memtime stamps per kernel segment).  Never shipped or timed."""
+    lib = os.path.join(HERE, "libmi_nerf_diag.so")
+    objs = [_compile(s, False, ("-DMN_DIAG",), "_diag") for s in SOURCES]
+    r = subprocess.run([_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", lib], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    return lib
+
+
 if __name__ == "__main__":
-    print(build_library(force="--force" in sys.argv, verbose=True))
+    if "--diag" in sys.argv:
+        print(build_diag_library())
+    else:
+        print(build_library(force="--force" in sys.argv, verbose=True))

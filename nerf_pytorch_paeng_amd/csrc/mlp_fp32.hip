@@ -14,6 +14,8 @@
 //   * gamma(x) is computed in registers per lane (sin on lanes 0-31, cos on lanes 32-63 of each k-step);
 //     in fused mode the view-direction block of linear_d is hoisted to a per-ray bias (it is constant
 //     over a ray's samples), density and colour heads run on the VALU as register dot products.
+#include <stdlib.h>
+#include <vector>
 #include "common.h"
 #include "layout.h"
 
@@ -38,6 +40,7 @@ struct MlpArgs {
     unsigned stream_bytes;    // hoisted or full length, multiple of SLOT_BYTES
     unsigned side_floats;
     unsigned o_bias_trunk, o_bias_feat, o_bias_d, o_dens_w, o_dens_b, o_color_w, o_color_b, o_wdir_t;
+    unsigned long long* diag;  // MN_DIAG builds only: per-wave segment cycle sums + one tile's k-quad stamps
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -54,46 +57,83 @@ struct MlpArgs {
 // (vmcnt retires in order), never under-wait.
 // ---------------------------------------------------------------------------------------------
 struct WRing {
-    const char* gsrc;       // per-lane global pointer: stream + wave*4 KiB + lane*16
-    unsigned fetch_off;     // stream byte offset of the next slot to fetch
+    const char* sbase;      // wave-uniform global pointer: stream + wave*4 KiB (the wave's quarter of every slot)
+    unsigned voff;          // per-lane byte offset inside a quad: lane*16
+    unsigned fetch_off;     // stream byte offset of the slot being fetched
     unsigned stream_bytes;
     unsigned fetch_lds;     // LDS byte address (wave-uniform) this wave's share of the next fetch lands at
     unsigned lds_lo, lds_hi;  // this wave's share of ring slot 0 / one past the last slot
     unsigned read_slot;     // ring slot being consumed
+#ifdef MN_DIAG
+    unsigned long long* dlog;   // fine-grained stamp log (one tile of one wave)
+    unsigned dcnt;
+#endif
 };
 
-__device__ __forceinline__ void dma16(const char* gptr, unsigned lds_addr) {
+#ifdef MN_DIAG
+// diagnostic build only (never shipped, never timed): s_memtime stamps around the kernel's segments.  A stamp drains
+// the LDS queue, so it perturbs what it measures (~100+ cycles each): read SHARES and DIFFERENCES, not totals.
+__device__ __forceinline__ unsigned long long mn_stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define MN_STAMP(i) do { const unsigned long long t_ = mn_stamp(); seg[i] += t_ - tprev; tprev = t_; } while (0)
+#define MN_KQ_STAMP(ring) do { if ((ring).dlog && (ring).dcnt < 500) { (ring).dlog[(ring).dcnt] = mn_stamp(); (ring).dcnt++; } } while (0)
+#else
+#define MN_STAMP(i) do {} while (0)
+#define MN_KQ_STAMP(ring) do {} while (0)
+#endif
+
+// one global_load_lds_dwordx4: 64 lanes x 16 B = one 1 KiB quad.  SGPR-base form: global address = sbase + voff + IMM,
+// LDS destination = M0 + IMM + lane*16 (the instruction offset applies to BOTH sides).  M0 is compiler-reserved:
+// saved and restored inside the statement.
+template <int IMM>
+__device__ __forceinline__ void dma16(const char* sbase, unsigned voff, unsigned lds_addr) {
     unsigned keep;
     asm volatile(
         "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %2\n\t"
+        "s_mov_b32 m0, %3\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, off\n\t"
+        "global_load_lds_dwordx4 %1, %2 offset:%4\n\t"
         "s_mov_b32 m0, %0"
         : "=&s"(keep)
-        : "v"(gptr), "s"(lds_addr)
+        : "v"(voff), "s"(sbase), "s"(lds_addr), "i"(IMM)
         : "memory");
 }
 
-__device__ __forceinline__ void dma_slot(WRing& r) {
-    const char* g = r.gsrc + r.fetch_off;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) dma16(g + i * QUAD_BYTES, r.fetch_lds + i * QUAD_BYTES);
+// DMA number I (0..3) of the slot being fetched
+template <int I>
+__device__ __forceinline__ void ring_dma(const WRing& r) {
+    dma16<I * QUAD_BYTES>(r.sbase + r.fetch_off, r.voff, r.fetch_lds);
+}
+
+__device__ __forceinline__ void ring_next_fetch(WRing& r) {
     r.fetch_off += SLOT_BYTES;
     if (r.fetch_off >= r.stream_bytes) r.fetch_off = 0;
     r.fetch_lds += SLOT_BYTES;
     if (r.fetch_lds >= r.lds_hi) r.fetch_lds = r.lds_lo;
 }
 
+// Start consuming the next slot.  The four DMAs of a slot are NOT issued here in a burst (every extra issue slot
+// between two MFMAs beyond ~8 delays the matrix pipe, tools/mfma_probe.hip): ring_read() issues DMA k together
+// with the read of the slot's quad k+1, i.e. spread over the four groups that follow the barrier.
 __device__ __forceinline__ void ring_advance(WRing& r) {
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __syncthreads();
-    dma_slot(r);
+    ring_next_fetch(r);
     r.read_slot = (r.read_slot + 1) & (NSLOT - 1);
 }
 
-__device__ __forceinline__ f32x4 ring_read(const char* smem, const WRing& r, int lane, int quad_in_slot) {
-    return *(const f32x4*)(smem + r.read_slot * SLOT_BYTES + lane * 16 + quad_in_slot * QUAD_BYTES);
+// qs is a compile-time constant at every call site once the GEMM loops are unrolled: the chain below folds away
+__device__ __forceinline__ f32x4 ring_read(const char* smem, const WRing& r, int lane, int qs) {
+    if (qs == 1) ring_dma<0>(r);
+    else if (qs == 2) ring_dma<1>(r);
+    else if (qs == 3) ring_dma<2>(r);
+    else if (qs == 4) ring_dma<3>(r);
+    return *(const f32x4*)(smem + r.read_slot * SLOT_BYTES + lane * 16 + qs * QUAD_BYTES);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -129,6 +169,7 @@ __device__ __forceinline__ void gemm_part(f32x16 (&acc)[8], const float (&b)[NB]
             // its first use and exposes the LDS latency on every tile
             __builtin_amdgcn_sched_barrier(0);
         }
+        MN_KQ_STAMP(ring);
     }
 #pragma unroll
     for (int t = NT; t < NT_NEXT; ++t) a[t] = ring_read(smem, ring, lane, t);
@@ -225,16 +266,20 @@ void mlp_fp32_kernel(const MlpArgs a) {
     if ((long long)blockIdx.x >= n_wg_tiles) return;     // host never launches such a block
 
     WRing ring;
-    ring.gsrc = a.stream + wave * (4 * QUAD_BYTES) + lane * 16;
+    ring.sbase = a.stream + wave * (4 * QUAD_BYTES);
+    ring.voff = lane * 16;
     ring.fetch_off = 0;
     ring.stream_bytes = a.stream_bytes;
     ring.lds_lo = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + wave * (4 * QUAD_BYTES);
     ring.lds_hi = ring.lds_lo + RING_BYTES;
     ring.fetch_lds = ring.lds_lo;
     ring.read_slot = NSLOT - 1;         // first ring_advance moves to slot 0
-    dma_slot(ring);
-    dma_slot(ring);
-    dma_slot(ring);
+    // slots 0..2 in bursts; from then on slot p+3 streams in, one DMA per group, while slot p is consumed
+#pragma unroll
+    for (int sl = 0; sl < 3; ++sl) {
+        if (sl) ring_next_fetch(ring);
+        ring_dma<0>(ring); ring_dma<1>(ring); ring_dma<2>(ring); ring_dma<3>(ring);
+    }
 
     f32x16 acc[8];
     f32x4 aq[8];                        // A-operand pipeline (gemm_part)
@@ -244,8 +289,16 @@ void mlp_fp32_kernel(const MlpArgs a) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) aq[t] = ring_read(smem, ring, lane, t);
 
+#ifdef MN_DIAG
+    unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = mn_stamp();
+#endif
     for (long long wgt = blockIdx.x; wgt < n_wg_tiles; wgt += gridDim.x) {
         long long wt = wgt * 4 + wave;
+#ifdef MN_DIAG
+        ring.dlog = (a.diag && wgt == (long long)blockIdx.x + 2 * gridDim.x && blockIdx.x < 4) ? a.diag + (size_t)gridDim.x * 32 + ((size_t)blockIdx.x * 4 + wave) * 512 : nullptr;
+        ring.dcnt = 0;
+#endif
         const bool wave_active = wt < a.n_wtiles;
         if (!wave_active) wt = a.n_wtiles - 1;
         bool valid;
@@ -297,9 +350,11 @@ void mlp_fp32_kernel(const MlpArgs a) {
             gather_regs<LD>(de, row + IN_X, hh, true);
         }
 
+        MN_STAMP(0);   // prologue
         // ---- trunk ----
         acc_init<NT>(acc, side + a.o_bias_trunk, hh);
         gemm_part<NT, KPE, NT>(acc, pe, aq, smem, ring, lane);
+        MN_STAMP(1);   // layer 0
 #pragma unroll 1
         for (int l = 1; l < a.D; ++l) {
             acc_to_b<NT, true>(acc, h);
@@ -308,12 +363,14 @@ void mlp_fp32_kernel(const MlpArgs a) {
             gemm_part<NT, HN, NT>(acc, h, aq, smem, ring, lane);
         }
         acc_to_b<NT, true>(acc, h);
+        MN_STAMP(2);   // trunk layers 1..D-1
         // ---- density head (VALU dot over the trunk output) ----
         const float dens = xhalf_sum(dot_half<HN>(h, side + a.o_dens_w, hh)) + side[a.o_dens_b];
         // ---- feature layer (no activation) ----
         acc_init<NT>(acc, side + a.o_bias_feat, hh);
         gemm_part<NT, HN, NT / 2>(acc, h, aq, smem, ring, lane);
         acc_to_b<NT, false>(acc, h);
+        MN_STAMP(3);   // density head + feature layer
         // ---- view-direction layer ----
         if constexpr (MODE == 0) {
             acc_init<NT / 2>(acc, scratch, hh);
@@ -325,6 +382,7 @@ void mlp_fp32_kernel(const MlpArgs a) {
         }
         float h2[HN / 2];
         acc_to_b<NT / 2, true>(acc, h2);
+        MN_STAMP(4);   // view-direction layer
         // ---- colour head ----
         const float* cw = side + a.o_color_w;
         const float r0 = xhalf_sum(dot_half<HN / 2>(h2, cw, hh)) + side[a.o_color_b + 0];
@@ -334,7 +392,14 @@ void mlp_fp32_kernel(const MlpArgs a) {
             f32x4 o; o[0] = r0; o[1] = r1; o[2] = r2; o[3] = dens;     // cat([rgb, density]) NeRF.py:51
             *(f32x4*)(a.out + out_idx * 4) = o;
         }
+        MN_STAMP(5);   // colour head + store
     }
+#ifdef MN_DIAG
+    if (a.diag && lane == 0) {
+        unsigned long long* d = a.diag + ((size_t)blockIdx.x * 4 + wave) * 8;
+        for (int i = 0; i < 8; ++i) d[i] = seg[i];
+    }
+#endif
     // the ring runs 3 slots ahead: let the last prefetches land before the workgroup's LDS is released
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -375,6 +440,41 @@ static int launch(const MlpArgs& args, long long n_wtiles, hipStream_t st) {
     }
     const long long n_wg = (n_wtiles + 3) / 4;
     const int grid = (int)(n_wg < (long long)num_cus() ? n_wg : (long long)num_cus());
+#ifdef MN_DIAG
+    {   // diagnostic build: run once with stamps and print the per-segment averages (cycles per tile per wave)
+        MlpArgs da = args;
+        unsigned long long* dbuf = nullptr;
+        const size_t n = (size_t)grid * 4 * 8 + 16 * 512;
+        MN_HIP(hipMalloc(&dbuf, n * 8));
+        MN_HIP(hipMemsetAsync(dbuf, 0, n * 8, st));
+        da.diag = dbuf;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, da);
+        MN_HIP(hipStreamSynchronize(st));
+        std::vector<unsigned long long> hbuf(n);
+        MN_HIP(hipMemcpy(hbuf.data(), dbuf, n * 8, hipMemcpyDeviceToHost));
+        (void)hipFree(dbuf);
+        const double tiles = (double)((n_wg + grid - 1) / grid);
+        static const char* names[6] = {"prologue", "layer0", "trunk", "dens+feature", "viewdir", "colour+store"};
+        double tot = 0;
+        fprintf(stderr, "[mn_diag] W=%d MODE=%d grid=%d tiles/wg=%.1f  cycles per tile (mean over waves):\n", W, MODE, grid, tiles);
+        for (int sgi = 0; sgi < 6; ++sgi) {
+            double sum = 0;
+            for (size_t w = 0; w < (size_t)grid * 4; ++w) sum += (double)hbuf[w * 8 + sgi];
+            const double per = sum / ((double)grid * 4) / tiles;
+            tot += per;
+            fprintf(stderr, "[mn_diag]   %-14s %10.0f\n", names[sgi], per);
+        }
+        fprintf(stderr, "[mn_diag]   %-14s %10.0f\n", "total", tot);
+        if (const char* e = getenv("MN_DIAG_KQ")) {      // per-k-quad stamp deltas of tile #2, block 0..3 wave e
+            const int wsel = atoi(e);
+            const unsigned long long* lg = hbuf.data() + (size_t)grid * 32 + (size_t)wsel * 512;
+            fprintf(stderr, "[mn_diag] k-quad deltas (cycles; ideal %d) of wave %d, tile 2:", 4 * 64 * (W / 32), wsel);
+            for (int i = 1; i < 500 && lg[i]; ++i) fprintf(stderr, "%s%llu", (i % 16 == 1) ? "\n[mn_diag]   " : " ", lg[i] - lg[i - 1]);
+            fprintf(stderr, "\n");
+        }
+        return MI_NERF_OK;
+    }
+#endif
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, args);
     MN_LAUNCH_CHECK("mlp_fp32_kernel");
     return MI_NERF_OK;
