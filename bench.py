@@ -64,11 +64,20 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one process per GPU; BENCH_BACKEND=gloo + fewer GPUs than ranks is only for rehearsing the multi-rank plumbing
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if world > ndev and backend == "nccl":
+        raise SystemExit(f"{world} ranks but {ndev} GPU(s): RCCL needs one GPU per rank")
+    dev = torch.device("cuda", local_rank % ndev)
+    torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")       # where the timing all-reduce lives
 
     from nerf_pytorch_paeng_amd import dist as mdist
     from nerf_pytorch_paeng_amd import nerf_process as NP
@@ -112,7 +121,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     rays_per_s = world * N_RAYS * args.steps / elapsed
@@ -155,7 +164,7 @@ def main():
         barrier()
         ft = time.perf_counter() - t0
         if world > 1:
-            tmax = torch.tensor([ft], dtype=torch.float64, device=dev)
+            tmax = torch.tensor([ft], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             ft = float(tmax.item())
         frame_ms = 1e3 * ft / args.frames

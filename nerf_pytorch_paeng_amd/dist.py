@@ -43,8 +43,12 @@ def gather_tiles(local: torch.Tensor, H: int, W: int, group=None) -> torch.Tenso
     if n_rows < max_rows:                                   # ragged split: pad to the common tile size
         padded = torch.zeros(max_rows * W, C, dtype=local.dtype, device=local.device)
         padded[:n_rows * W] = local
-    out = torch.empty(world * max_rows * W, C, dtype=local.dtype, device=local.device)
+    dev = local.device
+    if dev.type == "cuda" and dist.get_backend(group) == "gloo":     # CPU rehearsal of the multi-rank path
+        padded = padded.cpu()
+    out = torch.empty(world * max_rows * W, C, dtype=local.dtype, device=padded.device)
     dist.all_gather_into_tensor(out, padded.contiguous(), group=group)
+    out = out.to(dev)
     if H % world == 0:
         return out
     parts = []
