@@ -388,3 +388,33 @@ def test_pre_process_surface(packed_big, lego_rays):
     fused = NP.render_rays(rays, packed_big, posenc, opts, t_rand=t, u=u, return_intermediates=True)
     close(fused["_z_c"], z, 0); close(fused["rgb_c"], rgb, 2e-4)
     assert float((fused["_z_f"] - z_f).abs().max()) <= 1e-3
+
+
+# ---------------------------------------------------------------------------------------------------
+# bf16 MFMA variant (BASELINE config #5): bf16 weights/activations, fp32 accumulate -- compared with the fp32 path
+# ---------------------------------------------------------------------------------------------------
+def test_bf16_mlp_vs_fp32(packed_big, lego_rays):
+    n, S = 64, 192
+    rays = lego_rays[:n].contiguous()
+    z = torch.sort(T(R.counter_uniform(2, 0, 0, n, S)) * 4 + 2, -1)[0].to(DEV)
+    raw32 = ops.mlp_rays(packed_big.net, packed_big.fine, rays, z)
+    raw16 = ops.mlp_rays(packed_big.net, packed_big.bf16()[1], rays, z, bf16=True)
+    d = (raw16 - raw32).abs()
+    scale = float(raw32.abs().mean())
+    rel = float(d.mean()) / scale
+    print(f"bf16 vs fp32 raw: mean |diff| {float(d.mean()):.3e} (mean |raw| {scale:.3f}, relative {rel:.2e}), max {float(d.max()):.3e}")
+    assert torch.isfinite(raw16).all()
+    assert rel < 2e-2 and float(d.max()) < 0.5          # ~8 mantissa bits per product, averaged over 256-term sums
+
+
+def test_bf16_render_psnr(packed_big, lego_rays):
+    opts = make_opts()
+    a = NP.render_rays(lego_rays, packed_big, None, opts, seed=3, return_intermediates=True)
+    b = NP.render_rays(lego_rays, packed_big, None, opts, t_rand=a["_t_rand"], u=a["_u"], bf16=True)
+    for k in ("rgb_c", "rgb_f"):
+        mse = float(((a[k] - b[k]) ** 2).mean())
+        print(f"bf16 vs fp32 {k}: PSNR {R.mse2psnr(mse):.1f} dB, max |diff| {float((a[k] - b[k]).abs().max()):.3e}")
+        assert torch.isfinite(b[k]).all() and R.mse2psnr(mse) > 30.0
+    # odd sizes and determinism
+    c = NP.render_rays(lego_rays[:7].contiguous(), packed_big, None, opts, t_rand=a["_t_rand"][:7], u=a["_u"][:7], bf16=True)
+    assert torch.equal(c["rgb_f"], b["rgb_f"][:7])
