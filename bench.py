@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--frames", type=int, default=2, help="timed 800x800 frames (0 disables the frame metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--bf16", action="store_true", help="bf16 MFMA variant (BASELINE config #5)")
+    ap.add_argument("--workload", choices=["lego", "fern"], default="lego",
+                    help="lego: BASELINE config #2 (default, the headline metric); fern: config #4, LLFF geometry + NDC rays")
     return ap.parse_args()
 
 
@@ -90,14 +92,18 @@ def main():
     # ---- inputs (resident in HBM before any timed region) ----------------------------------------------
     sd = synthetic.make_state_dict(0, 8, 256)
     packed = weights.PackedNeRF.from_state_dict(sd, dev)
-    K, H, W = synthetic.lego_camera()
-    pose = synthetic.pose_spherical(0.0, -30.0, 4.0)
+    fern = args.workload == "fern"
+    K, H, W = synthetic.fern_camera() if fern else synthetic.lego_camera()
+    pose = synthetic.fern_pose() if fern else synthetic.pose_spherical(0.0, -30.0, 4.0)
     pix_all = synthetic.pixel_batch(H, W, N_RAYS * world, 0)                # each rank gets its own 4096 pixels
     pix = torch.from_numpy(pix_all[rank * N_RAYS:(rank + 1) * N_RAYS]).to(dev)
     o, d = ops.make_o_d_pixels(W, H, K, pose, pix)
+    if fern:                                                                # NDC warp, near plane 1 (nerf_process.py:224-226)
+        o, d = ops.ndc_rays(H, W, float(K[0][0]), 1.0, o, d)
     rays = torch.cat([o, d], -1).contiguous()
-    opts = SimpleNamespace(near=2.0, far=6.0, N_samples_c=SC, N_samples_f=NF, perturb=1.0, chunk_rays=N_RAYS,
-                           chunk_pts=524288, data_type="blender", gpu_ids=list(range(world)), rank=rank)
+    opts = SimpleNamespace(near=0.0 if fern else 2.0, far=1.0 if fern else 6.0, N_samples_c=SC, N_samples_f=NF, perturb=1.0,
+                           chunk_rays=N_RAYS, chunk_pts=524288, data_type="llff" if fern else "blender",
+                           gpu_ids=list(range(world)), rank=rank)
     cfg = ops.render_cfg(opts.near, opts.far, SC, NF, False, args.bf16)
     t_rand = ops.fill_uniform(0, 0, rank * N_RAYS, N_RAYS, SC, dev)
     u = ops.fill_uniform(0, 1, rank * N_RAYS, N_RAYS, NF, dev)
@@ -159,7 +165,8 @@ def main():
         barrier()
         t0 = time.perf_counter()
         for f in range(args.frames):
-            rgb, disp = mdist.render_frame(H, W, K, synthetic.pose_spherical(3.0 * (f + 1), -30.0, 4.0), packed, opts, seed=0, bf16=args.bf16)
+            fpose = synthetic.fern_pose() if fern else synthetic.pose_spherical(3.0 * (f + 1), -30.0, 4.0)
+            rgb, disp = mdist.render_frame(H, W, K, fpose, packed, opts, seed=0, bf16=args.bf16)
         torch.cuda.synchronize(dev)
         barrier()
         ft = time.perf_counter() - t0
@@ -198,10 +205,13 @@ def main():
             "value": round(rays_per_s, 1), "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if args.bf16 else "f32", "data": "synthetic",
-            "config": {"workload": "lego coarse+fine 4096 rays per GPU, 64+128 samples, 8x256 MLP (BASELINE config #2)",
+            "config": {"workload": ("fern LLFF NDC rays, coarse+fine 4096 rays per GPU, 64+128 samples, 8x256 MLP (BASELINE config #4)" if fern else
+                                    "lego coarse+fine 4096 rays per GPU, 64+128 samples, 8x256 MLP (BASELINE config #2)") +
+                                   (" -- bf16 MFMA variant (config #5)" if args.bf16 else ""),
                        "rays_per_gpu": N_RAYS, "samples": [SC, NF], "net": "8x256, skip 4, L_x 10, L_d 4",
                        "parallelism": f"rays sharded over {world} GPU(s), no data-path collective"},
-            "frame_ms_800x800": None if frame_ms is None else round(frame_ms, 2),
+            "frame_ms_800x800": None if (frame_ms is None or fern) else round(frame_ms, 2),
+            "frame_ms": None if frame_ms is None else round(frame_ms, 2), "frame_hw": [H, W],
             "frac_of_f32_mfma_roofline_end_to_end": round(rays_per_s / world * FLOP_PER_RAY / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
             "roofline": roofline,
         }
