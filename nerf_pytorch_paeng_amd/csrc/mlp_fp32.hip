@@ -188,12 +188,22 @@ __device__ __forceinline__ void acc_init(f32x16 (&acc)[8], const float* vec_lds,
         }
 }
 
+// ReLU as ONE integer instruction, pinned where it is written (volatile): max_i32(bits, 0) keeps every non-negative
+// float (and +NaN) and maps negatives and -0.0 to +0.0.  A plain fmaxf() costs two instructions (hipcc canonicalises
+// the MFMA output first) and hipcc defers them to directly in front of the MFMA that consumes the value, which then
+// waits out the VALU latency plus hazard nops: ~20 cycles per k-step in the trunk layers (MN_DIAG stamps).
+__device__ __forceinline__ float relu_pinned(float x) {
+    float r;
+    asm volatile("v_max_i32 %0, 0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
 template <int NT, bool RELU, int NB>
 __device__ __forceinline__ void acc_to_b(const f32x16 (&acc)[8], float (&h)[NB]) {
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) h[16 * t + r] = RELU ? __builtin_fmaxf(acc[t][r], 0.0f) : acc[t][r];
+        for (int r = 0; r < 16; ++r) h[16 * t + r] = RELU ? relu_pinned(acc[t][r]) : acc[t][r];
 }
 
 // sum_i h[i] * w[feat(i, hh)] over this lane's half; w natural order in LDS
