@@ -303,6 +303,28 @@ void mlp_fp32_kernel(const MlpArgs a) {
     unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tprev = mn_stamp();
 #endif
+    // MODE 0 tile walk without a 64-bit division per tile: wave tile wt = (ray, chunk) advances by gridDim*4 per step.
+    // The inputs of the NEXT tile (six ray scalars, one depth per lane) are loaded a whole tile ahead.
+    long long t_ray = 0, step_ray = 0;
+    int t_chunk = 0, step_chunk = 0;
+    float nx_o[3] = {0.f, 0.f, 0.f}, nx_d[3] = {0.f, 0.f, 0.f}, nx_z = 0.f;
+    auto tile_inputs = [&](long long ray, int chunk) __attribute__((always_inline)) {
+        const int sample = chunk * 32 + col;
+        const int sc = sample < a.S ? sample : a.S - 1;
+        const float* rp = a.rays + ray * 6;
+        nx_o[0] = rp[0]; nx_o[1] = rp[1]; nx_o[2] = rp[2]; nx_d[0] = rp[3]; nx_d[1] = rp[4]; nx_d[2] = rp[5];
+        nx_z = a.z[ray * a.S + sc];
+    };
+    if constexpr (MODE == 0) {
+        long long wt0 = (long long)blockIdx.x * 4 + wave;
+        if (wt0 >= a.n_wtiles) wt0 = a.n_wtiles - 1;
+        t_ray = wt0 / a.tpr;
+        t_chunk = (int)(wt0 - t_ray * a.tpr);
+        const long long step = (long long)gridDim.x * 4;
+        step_ray = step / a.tpr;
+        step_chunk = (int)(step - step_ray * a.tpr);
+        tile_inputs(t_ray, t_chunk);
+    }
     for (long long wgt = blockIdx.x; wgt < n_wg_tiles; wgt += gridDim.x) {
         long long wt = wgt * 4 + wave;
 #ifdef MN_DIAG
@@ -315,14 +337,19 @@ void mlp_fp32_kernel(const MlpArgs a) {
         long long out_idx;
         float de[KDE];
         if constexpr (MODE == 0) {
-            const long long ray = wt / a.tpr;
-            const int sample = (int)(wt - ray * a.tpr) * 32 + col;
+            const long long ray = t_ray;
+            const int sample = t_chunk * 32 + col;
             valid = wave_active && sample < a.S;
             const int sc = sample < a.S ? sample : a.S - 1;
             out_idx = ray * a.S + sc;
-            const float* rp = a.rays + ray * 6;
-            const float ox = rp[0], oy = rp[1], oz = rp[2], dx = rp[3], dy = rp[4], dz = rp[5];
-            const float zv = a.z[out_idx];
+            const float ox = nx_o[0], oy = nx_o[1], oz = nx_o[2], dx = nx_d[0], dy = nx_d[1], dz = nx_d[2];
+            const float zv = nx_z;
+            // advance to this wave's next tile and start loading its inputs now (clamped: the tail re-reads the last tile)
+            t_ray += step_ray;
+            t_chunk += step_chunk;
+            if (t_chunk >= a.tpr) { t_chunk -= a.tpr; t_ray += 1; }
+            if (t_ray * a.tpr + t_chunk >= a.n_wtiles) { t_ray = (a.n_wtiles - 1) / a.tpr; t_chunk = (int)((a.n_wtiles - 1) - t_ray * a.tpr); }
+            tile_inputs(t_ray, t_chunk);
             // pts = rays_o + rays_d * z : separate multiply and add (nerf_process.py:69-70), no contraction
             const float p[3] = {ox + dx * zv, oy + dy * zv, oz + dz * zv};
             const float amax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(p[0]), __builtin_fabsf(p[1])), __builtin_fabsf(p[2])) * (float)(1 << (LX - 1));
