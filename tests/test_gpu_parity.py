@@ -418,3 +418,62 @@ def test_bf16_render_psnr(packed_big, lego_rays):
     # odd sizes and determinism
     c = NP.render_rays(lego_rays[:7].contiguous(), packed_big, None, opts, t_rand=a["_t_rand"][:7], u=a["_u"][:7], bf16=True)
     assert torch.equal(c["rgb_f"], b["rgb_f"][:7])
+
+
+# ---------------------------------------------------------------------------------------------------
+# other network shapes, the frame harness, error behaviour
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("D,W", [(6, 128), (2, 128), (3, 256), (10, 256)])
+def test_other_network_shapes(D, W):
+    """skip=[4] only fires when D >= 6 (model/NeRF.py:25 builds range(D-1)); depth is a run-time loop in the kernel."""
+    sd = synthetic.make_state_dict(21, D, W)
+    packed = weights.PackedNeRF.from_state_dict(sd, DEV)
+    assert packed.net.skip == (4 if D >= 6 else -1)
+    x = torch.rand(100, 90) * 2 - 1
+    y = ops.mlp_embedded(packed.net, packed.coarse, x.to(DEV))
+    ref = R.mlp_forward(sd, "model_coarse.", x, D, 63, 27, dtype=torch.float64)
+    assert err(y, ref) <= 5e-5
+    rays = torch.cat([torch.rand(9, 3) * 2 - 1, torch.nn.functional.normalize(torch.randn(9, 3), dim=-1)], -1)
+    z = torch.sort(torch.rand(9, 64) * 4 + 2, -1)[0]
+    raw = ops.mlp_rays(packed.net, packed.fine, rays.to(DEV), z.to(DEV))
+    ref = R.mlp_forward(sd, "model_fine.", R.embed(rays, z, 10, 4).double(), D, 63, 27, dtype=torch.float64).reshape(9, 64, 4)
+    assert err(raw, ref) <= 1e-4
+
+
+def test_frame_harness_rows_and_llff(packed_big):
+    """dist.render_frame (the counterpart of test.py:38-53) on one process: a frame rendered whole equals the same frame
+    rendered as two row blocks with global ray offsets; llff mode runs the NDC warp."""
+    from nerf_pytorch_paeng_amd import dist as mdist
+    for data_type, (K, H, W), pose, nf in (("blender", synthetic.lego_camera(), synthetic.pose_spherical(30.0, -30.0, 4.0), (2.0, 6.0)),
+                                             ("llff", synthetic.fern_camera(), synthetic.fern_pose(), (0.0, 1.0))):
+        s = 24.0 / W
+        Ks = K.copy(); Ks[0, 0] *= s; Ks[1, 1] *= s; Ks[0, 2] = 12.0; Ks[1, 2] = 10.0
+        h, w = 20, 24
+        opts = make_opts(near=nf[0], far=nf[1], data_type=data_type)
+        rgb, disp = mdist.render_frame(h, w, Ks, pose, packed_big, opts, seed=5)
+        assert rgb.shape == (h, w, 3) and disp.shape == (h, w) and torch.isfinite(rgb).all()
+        top = mdist.render_frame(h, w, Ks, pose, packed_big, opts, seed=5, render_rows_fn=None)[0]
+        assert torch.equal(top, rgb)
+        # two row blocks by hand
+        parts = []
+        for r0, nr in ((0, 7), (7, 13)):
+            _, d = ops.make_o_d(w, h, Ks, pose, DEV, row0=r0, n_rows=nr, want_origins=False)
+            o = torch.as_tensor(pose)[:3, -1].to(DEV).expand(d.shape)
+            out = NP.batchify_rays_and_render_by_chunk(o, d, packed_big, None, h, w, Ks, opts, seed=5, ray_offset=r0 * w)
+            parts.append(out[2])
+        assert torch.equal(torch.cat(parts, 0).reshape(h, w, 3), rgb)
+
+
+def test_error_behaviour(packed_big, lego_rays):
+    from nerf_pytorch_paeng_amd._lib import MiNerfError
+    opts = make_opts()
+    with pytest.raises(MiNerfError):
+        NP.render_rays(lego_rays[:4, :5].contiguous(), packed_big, None, opts)                 # not [n, 6]
+    with pytest.raises(MiNerfError):
+        ops.mlp_embedded(packed_big.net, packed_big.coarse, torch.rand(4, 63, device=DEV))        # wrong channel count
+    with pytest.raises(MiNerfError):
+        ops.sample_pdf(torch.rand(4, 8, device=DEV), torch.rand(4, 8, device=DEV), 16, False, None)   # weights must be B-1, u needed
+    with pytest.raises(MiNerfError):
+        weights.PackedNeRF.from_state_dict(synthetic.make_state_dict(0, 4, 64), DEV)               # unsupported width
+    with pytest.raises(MiNerfError):
+        NP.render_rays(lego_rays[:4].cpu(), weights.packed_for(packed_big), None, opts, t_rand=torch.rand(4, 63))   # wrong t_rand shape

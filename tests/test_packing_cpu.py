@@ -90,3 +90,18 @@ def test_blob_emulation_matches_oracle_fused():
     x = torch.cat([R.posenc(torch.from_numpy(p.T.copy()), 10), torch.from_numpy(g)[None].expand(32, 27)], -1)
     ref = R.mlp_forward(sd, "model_coarse.", x, D, 63, 27, dtype=torch.float64).numpy()
     np.testing.assert_allclose(out, ref, atol=1e-9, rtol=1e-9)
+
+
+def test_model_mirror_has_reference_checkpoint_keys():
+    """The NeRF mirror must accept the reference's checkpoints: same state_dict keys and shapes as model/NeRF.py:24-30,58-59."""
+    from nerf_pytorch_paeng_amd.model import NeRF
+    for D, W in ((8, 256), (4, 128)):
+        m = NeRF(D, W, 63, 27, skips=[4], gt_camera_param=(None, None))
+        sd = synthetic.make_state_dict(0, D, W)
+        got = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+        want = {k: tuple(v.shape) for k, v in sd.items()}
+        assert got == want
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        assert m.get_camera_gt() == (None, None)
+    with pytest.raises(_lib.MiNerfError):        # parameters on CPU: the MI355X path refuses, it never falls back
+        m(torch.rand(2, 90))
