@@ -160,6 +160,15 @@ typedef struct mi_nerf_workspace_layout {
 } mi_nerf_workspace_layout;
 int mi_nerf_render_workspace_layout(const mi_nerf_render_cfg* cfg, int64_t n_rays, mi_nerf_workspace_layout* out);
 
+/* ------------------------------------------------------------------------------------------------
+ * Training path: what `loss.backward()` does for the hot path in
+ * train.py:53-70.  Only rgb_map carries gradient (the loss reads pred_rgb_c / pred_rgb_f); depths are
+ * constants (coarse: no graph; fine: detached at nerf_process.py:66).
+ * ---------------------------------------------------------------------------------------------- */
+/* backward of mi_nerf_composite w.r.t. raw: d_rgb [n,3] -> d_raw [n,S,4]   (autograd of nerf_process.py:89-140) */
+int mi_nerf_composite_backward(const float* raw_dev, const float* z_dev, const float* rays_dev, int ray_stride,
+                               int64_t n, int S, const float* d_rgb_dev, float* d_raw_dev, void* stream);
+
 /* Timing hook used by bench.py: average device time (ms) of `iters` back-to-back launches of the fused MLP
  * kernel on `stream`, measured with hipEvents recorded on that same stream (torch.cuda.Event only sees
  * torch's current stream).  Synchronises the stream. */

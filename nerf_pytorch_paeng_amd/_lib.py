@@ -70,6 +70,7 @@ SIGNATURES = {
     "mi_nerf_render_workspace_bytes": (_SZ, [_CFGP, _I64]),
     "mi_nerf_render_rays": (_I, [_NETP, _P, _P, _CFGP, _P, _I64, _P, _P, _P, _SZ, _P, _P, _P, _P, _P]),
     "mi_nerf_render_workspace_layout": (_I, [_CFGP, _I64, C.POINTER(WorkspaceLayout)]),
+    "mi_nerf_composite_backward": (_I, [_P, _P, _P, _I, _I64, _I, _P, _P, _P]),
     "mi_nerf_time_mlp_rays": (_I, [_NETP, _P, _P, _P, _I64, _I, _P, _I, _I, C.POINTER(_F), _P]),
     "mi_nerf_selftest_mfma": (_I, [_P]),
 }

@@ -34,6 +34,7 @@ int stage_stratified(int64_t, int, float, float, const float*, float*, hipStream
 int stage_embed(const float*, const float*, int64_t, int, int, int, float*, hipStream_t);
 int stage_posenc(const float*, int64_t, int, float*, hipStream_t);
 int stage_composite(const float*, const float*, const float*, int, int64_t, int, float*, float*, float*, float*, float*, hipStream_t);
+int stage_composite_backward(const float*, const float*, const float*, int, int64_t, int, const float*, float*, hipStream_t);
 int stage_sample_pdf(const float*, const float*, int64_t, int, int, int, const float*, float*, hipStream_t);
 int stage_fine_z(const float*, const float*, int64_t, int, int, int, const float*, float*, float*, hipStream_t);
 
@@ -161,6 +162,11 @@ int mi_nerf_mlp_rays_bf16(const mi_nerf_net* net, const void* packed, const floa
 int mi_nerf_composite(const float* raw, const float* z, const float* rays, int ray_stride, int64_t n, int S, float* rgb, float* disp,
                       float* acc, float* weights, float* depth, void* st) {
     return stage_composite(raw, z, rays, ray_stride, n, S, rgb, disp, acc, weights, depth, (hipStream_t)st);
+}
+
+int mi_nerf_composite_backward(const float* raw, const float* z, const float* rays, int ray_stride, int64_t n, int S,
+                               const float* d_rgb, float* d_raw, void* st) {
+    return stage_composite_backward(raw, z, rays, ray_stride, n, S, d_rgb, d_raw, (hipStream_t)st);
 }
 
 size_t mi_nerf_render_workspace_bytes(const mi_nerf_render_cfg* cfg, int64_t n_rays) {

@@ -18,11 +18,11 @@
 #include <vector>
 #include "common.h"
 #include "layout.h"
+#include "mlp_core.h"
+
 
 namespace minerf {
 
-constexpr int NSLOT = 4;
-constexpr int RING_BYTES = NSLOT * SLOT_BYTES;
 
 struct MlpArgs {
     const char* stream;       // device: blob + stream_off
@@ -41,187 +41,13 @@ struct MlpArgs {
     unsigned side_floats;
     unsigned o_bias_trunk, o_bias_feat, o_bias_d, o_dens_w, o_dens_b, o_color_w, o_color_b, o_wdir_t;
     unsigned long long* diag;  // MN_DIAG builds only: per-wave segment cycle sums + one tile's k-quad stamps
+    // STASH kernels (training forward): row-major activations kept for the backward pass, P = stash_rows points
+    float* stash_h;           // [D][P][W]   post-ReLU output of trunk layer l
+    float* stash_f;           // [P][W]      linear_feat output
+    float* stash_g;           // [P][W/2]    post-ReLU linear_d output
+    long long stash_rows;
 };
 
-// ---------------------------------------------------------------------------------------------
-// weight ring: NSLOT x 16 KiB in LDS, filled by LDS-DMA three slots ahead of the consumer.
-//
-// The DMA is issued from inline asm so that hipcc neither counts it (a counted DMA makes every
-// __syncthreads() drain vmcnt(0), i.e. wait for the prefetch just issued) nor moves it; we count it
-// ourselves: each ring_advance issues exactly 4 global_load_lds_dwordx4 per wave and waits vmcnt(4)
-// before the barrier, i.e. for everything except the 4 issued at the previous advance.
-//   advance to slot p: [vmcnt(4)] -> slots <= p+1 of this wave's share have landed; barrier -> of every
-//   wave's share, and every wave has completed its LDS reads of slot p-1 (lgkmcnt(0) is part of the
-//   barrier); then fetch slot p+3 into ring[(p+3)&3] == ring[(p-1)&3].
-// Compiler-counted loads/stores elsewhere in the kernel only ever over-wait because of the uncounted DMA
-// (vmcnt retires in order), never under-wait.
-// ---------------------------------------------------------------------------------------------
-struct WRing {
-    const char* sbase;      // wave-uniform global pointer: stream + wave*4 KiB (the wave's quarter of every slot)
-    unsigned voff;          // per-lane byte offset inside a quad: lane*16
-    unsigned fetch_off;     // stream byte offset of the slot being fetched
-    unsigned stream_bytes;
-    unsigned fetch_lds;     // LDS byte address (wave-uniform) this wave's share of the next fetch lands at
-    unsigned lds_lo, lds_hi;  // this wave's share of ring slot 0 / one past the last slot
-    unsigned read_slot;     // ring slot being consumed
-#ifdef MN_DIAG
-    unsigned long long* dlog;   // fine-grained stamp log (one tile of one wave)
-    unsigned dcnt;
-#endif
-};
-
-#ifdef MN_DIAG
-// diagnostic build only (never shipped, never timed): s_memtime stamps around the kernel's segments.  A stamp drains
-// the LDS queue, so it perturbs what it measures (~100+ cycles each): read SHARES and DIFFERENCES, not totals.
-__device__ __forceinline__ unsigned long long mn_stamp() {
-    unsigned long long t;
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-    __builtin_amdgcn_sched_barrier(0);
-    return t;
-}
-#define MN_STAMP(i) do { const unsigned long long t_ = mn_stamp(); seg[i] += t_ - tprev; tprev = t_; } while (0)
-#define MN_KQ_STAMP(ring) do { if ((ring).dlog && (ring).dcnt < 500) { (ring).dlog[(ring).dcnt] = mn_stamp(); (ring).dcnt++; } } while (0)
-#else
-#define MN_STAMP(i) do {} while (0)
-#define MN_KQ_STAMP(ring) do {} while (0)
-#endif
-
-// one global_load_lds_dwordx4: 64 lanes x 16 B = one 1 KiB quad.  SGPR-base form: global address = sbase + voff + IMM,
-// LDS destination = M0 + IMM + lane*16 (the instruction offset applies to BOTH sides).  M0 is compiler-reserved:
-// saved and restored inside the statement.
-template <int IMM>
-__device__ __forceinline__ void dma16(const char* sbase, unsigned voff, unsigned lds_addr) {
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %3\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %2 offset:%4\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(voff), "s"(sbase), "s"(lds_addr), "i"(IMM)
-        : "memory");
-}
-
-// DMA number I (0..3) of the slot being fetched
-template <int I>
-__device__ __forceinline__ void ring_dma(const WRing& r) {
-    dma16<I * QUAD_BYTES>(r.sbase + r.fetch_off, r.voff, r.fetch_lds);
-}
-
-__device__ __forceinline__ void ring_next_fetch(WRing& r) {
-    r.fetch_off += SLOT_BYTES;
-    if (r.fetch_off >= r.stream_bytes) r.fetch_off = 0;
-    r.fetch_lds += SLOT_BYTES;
-    if (r.fetch_lds >= r.lds_hi) r.fetch_lds = r.lds_lo;
-}
-
-// Start consuming the next slot.  The four DMAs of a slot are NOT issued here in a burst (every extra issue slot
-// between two MFMAs beyond ~8 delays the matrix pipe, tools/mfma_probe.hip): ring_read() issues DMA k together
-// with the read of the slot's quad k+1, i.e. spread over the four groups that follow the barrier.
-__device__ __forceinline__ void ring_advance(WRing& r) {
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    __syncthreads();
-    ring_next_fetch(r);
-    r.read_slot = (r.read_slot + 1) & (NSLOT - 1);
-}
-
-// qs is a compile-time constant at every call site once the GEMM loops are unrolled: the chain below folds away
-__device__ __forceinline__ f32x4 ring_read(const char* smem, const WRing& r, int lane, int qs) {
-    if (qs == 1) ring_dma<0>(r);
-    else if (qs == 2) ring_dma<1>(r);
-    else if (qs == 3) ring_dma<2>(r);
-    else if (qs == 4) ring_dma<3>(r);
-    return *(const f32x4*)(smem + r.read_slot * SLOT_BYTES + lane * 16 + qs * QUAD_BYTES);
-}
-
-// ---------------------------------------------------------------------------------------------
-// one GEMM part: acc[0..NT) += A(stream) x B, B = KS per-lane registers b[0..KS).
-// `a` is the A-operand pipeline: on entry it holds this part's quads (kq=0, t<NT), already read from
-// LDS; after the 4 MFMAs that consume a[t] the quad NT positions further down the stream is read into
-// it, so every LDS read has a full k-quad (NT*4 MFMAs) of lead time.  On exit `a` holds the first
-// NT_NEXT quads of the NEXT part (parts are slot aligned, the stream is consumed strictly in order).
-// MFMA order is t-major: 4 back-to-back dependent MFMAs per tile (dependent issue = 64 cycles = the
-// issue interval of v_mfma_f32_32x32x2_f32, so the chain costs nothing).
-// ---------------------------------------------------------------------------------------------
-template <int NT, int KS, int NT_NEXT, int NB>
-__device__ __forceinline__ void gemm_part(f32x16 (&acc)[8], const float (&b)[NB], f32x4 (&a)[8], const char* smem,
-                                          WRing& ring, int lane) {
-    static_assert(KS % 4 == 0 && KS <= NB, "k-steps come in quads");
-    constexpr int KQ = KS / 4;
-#pragma unroll
-    for (int kq = 0; kq < KQ; ++kq) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][j], b[4 * kq + j], acc[t], 0, 0, 0);
-            if (kq + 1 < KQ) {
-                const int q = (kq + 1) * NT + t;                       // quad index inside this part
-                if (q % SLOT_QUADS == 0) ring_advance(ring);
-                a[t] = ring_read(smem, ring, lane, q % SLOT_QUADS);
-            } else if (t < NT_NEXT) {
-                if (t == 0) ring_advance(ring);                        // next part starts a fresh slot
-                a[t] = ring_read(smem, ring, lane, t);
-            }
-            // pin the (4 MFMA, 1 LDS read) group order: left alone, hipcc sinks each read to just before
-            // its first use and exposes the LDS latency on every tile
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        MN_KQ_STAMP(ring);
-    }
-#pragma unroll
-    for (int t = NT; t < NT_NEXT; ++t) a[t] = ring_read(smem, ring, lane, t);
-}
-
-// acc tile t <- 32 floats of a natural-order vector in LDS (bias): register r of lane half hh holds
-// feature 32t + (r&3) + 8*(r>>2) + 4*hh  -> four 16-byte reads at 32t + 8g + 4hh.
-template <int NT>
-__device__ __forceinline__ void acc_init(f32x16 (&acc)[8], const float* vec_lds, int hh) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 v = *(const f32x4*)(vec_lds + 32 * t + 8 * g + 4 * hh);
-            acc[t][4 * g + 0] = v[0]; acc[t][4 * g + 1] = v[1]; acc[t][4 * g + 2] = v[2]; acc[t][4 * g + 3] = v[3];
-        }
-}
-
-// ReLU as ONE integer instruction, pinned where it is written (volatile): max_i32(bits, 0) keeps every non-negative
-// float (and +NaN) and maps negatives and -0.0 to +0.0.  A plain fmaxf() costs two instructions (hipcc canonicalises
-// the MFMA output first) and hipcc defers them to directly in front of the MFMA that consumes the value, which then
-// waits out the VALU latency plus hazard nops: ~20 cycles per k-step in the trunk layers (MN_DIAG stamps).
-__device__ __forceinline__ float relu_pinned(float x) {
-    float r;
-    asm volatile("v_max_i32 %0, 0, %1" : "=v"(r) : "v"(x));
-    return r;
-}
-
-template <int NT, bool RELU, int NB>
-__device__ __forceinline__ void acc_to_b(const f32x16 (&acc)[8], float (&h)[NB]) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) h[16 * t + r] = RELU ? relu_pinned(acc[t][r]) : acc[t][r];
-}
-
-// sum_i h[i] * w[feat(i, hh)] over this lane's half; w natural order in LDS
-template <int N, int NB>
-__device__ __forceinline__ float dot_half(const float (&h)[NB], const float* w_lds, int hh) {
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-#pragma unroll
-    for (int q = 0; q < N / 4; ++q) {        // q = 4t + g : features 32t + 8g + 4hh + {0..3}
-        const f32x4 w = *(const f32x4*)(w_lds + 8 * q + 4 * hh);
-        s0 = __builtin_fmaf(h[4 * q + 0], w[0], s0);
-        s1 = __builtin_fmaf(h[4 * q + 1], w[1], s1);
-        s2 = __builtin_fmaf(h[4 * q + 2], w[2], s2);
-        s3 = __builtin_fmaf(h[4 * q + 3], w[3], s3);
-    }
-    return (s0 + s1) + (s2 + s3);
-}
-
-__device__ __forceinline__ float xhalf_sum(float v) { return v + __shfl_xor(v, 32, 64); }
 
 // encoded-input registers for k-step s: level k = s/3, axis c = s%3
 template <int L, bool SLOW, int NPE>
@@ -254,7 +80,7 @@ __device__ __forceinline__ void gather_regs(float (&pe)[NPE], const float* row, 
 // ---------------------------------------------------------------------------------------------
 // the kernel.  MODE 0: rays + z (fused posenc, hoisted view-direction bias).  MODE 1: embedded rows.
 // ---------------------------------------------------------------------------------------------
-template <int W, int MODE, int LX, int LD>
+template <int W, int MODE, int LX, int LD, bool STASH>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void mlp_fp32_kernel(const MlpArgs a) {
     constexpr int NT = W / 32;          // output tiles of a W-wide layer
@@ -395,11 +221,13 @@ void mlp_fp32_kernel(const MlpArgs a) {
 #pragma unroll 1
         for (int l = 1; l < a.D; ++l) {
             acc_to_b<NT, true>(acc, h);
+            if constexpr (STASH) store_rows<NT>(h, a.stash_h + ((long long)(l - 1) * a.stash_rows + out_idx) * W + 4 * hh, valid);
             acc_init<NT>(acc, side + a.o_bias_trunk + l * W, hh);
             if (l == a.skip_layer) gemm_part<NT, KPE, NT>(acc, pe, aq, smem, ring, lane);   // cat([gamma(x), h]) order
             gemm_part<NT, HN, NT>(acc, h, aq, smem, ring, lane);
         }
         acc_to_b<NT, true>(acc, h);
+        if constexpr (STASH) store_rows<NT>(h, a.stash_h + ((long long)(a.D - 1) * a.stash_rows + out_idx) * W + 4 * hh, valid);
         MN_STAMP(2);   // trunk layers 1..D-1
         // ---- density head (VALU dot over the trunk output) ----
         const float dens = xhalf_sum(dot_half<HN>(h, side + a.o_dens_w, hh)) + side[a.o_dens_b];
@@ -407,6 +235,7 @@ void mlp_fp32_kernel(const MlpArgs a) {
         acc_init<NT>(acc, side + a.o_bias_feat, hh);
         gemm_part<NT, HN, NT / 2>(acc, h, aq, smem, ring, lane);
         acc_to_b<NT, false>(acc, h);
+        if constexpr (STASH) store_rows<NT>(h, a.stash_f + out_idx * W + 4 * hh, valid);
         MN_STAMP(3);   // density head + feature layer
         // ---- view-direction layer ----
         if constexpr (MODE == 0) {
@@ -419,6 +248,7 @@ void mlp_fp32_kernel(const MlpArgs a) {
         }
         float h2[HN / 2];
         acc_to_b<NT / 2, true>(acc, h2);
+        if constexpr (STASH) store_rows<NT / 2>(h2, a.stash_g + out_idx * (W / 2) + 4 * hh, valid);
         MN_STAMP(4);   // view-direction layer
         // ---- colour head ----
         const float* cw = side + a.o_color_w;
@@ -465,11 +295,11 @@ static int num_cus() {
     return cus;
 }
 
-template <int W, int MODE>
+template <int W, int MODE, bool STASH = false>
 static int launch(const MlpArgs& args, long long n_wtiles, hipStream_t st) {
     const size_t lds = RING_BYTES + (size_t)args.side_floats * 4 + 4 * (W / 2) * 4;
     MN_CHECK_ARG(lds <= 160 * 1024, "LDS budget exceeded: %zu bytes", lds);
-    auto kern = mlp_fp32_kernel<W, MODE, 10, 4>;
+    auto kern = mlp_fp32_kernel<W, MODE, 10, 4, STASH>;
     static bool attr_set = false;
     if (!attr_set) {
         MN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -541,6 +371,21 @@ int mlp_rays_fp32(const mi_nerf_net* net, const void* packed_dev, const float* r
     a.rays = rays_dev; a.z = z_dev; a.out = raw_dev; a.S = S; a.tpr = (S + 31) / 32;
     a.n_wtiles = (long long)n_rays * a.tpr;
     return net->W == 256 ? launch<256, 0>(a, a.n_wtiles, st) : launch<128, 0>(a, a.n_wtiles, st);
+}
+
+// training forward: same kernel, additionally keeping every layer's activations row-major for the backward pass
+int mlp_rays_fp32_stash(const mi_nerf_net* net, const void* packed_dev, const float* rays_dev, const float* z_dev,
+                        int64_t n_rays, int S, float* raw_dev, float* stash_h, float* stash_f, float* stash_g, hipStream_t st) {
+    if (int rc = check_net(net)) return rc;
+    MN_CHECK_ARG(n_rays >= 0 && S >= 1, "bad sizes n_rays=%lld S=%d", (long long)n_rays, S);
+    if (n_rays == 0) return MI_NERF_OK;
+    MN_CHECK_ARG(packed_dev && rays_dev && z_dev && raw_dev && stash_h && stash_f && stash_g, "NULL device pointer");
+    MlpArgs a{};
+    fill_common(a, net, packed_dev, false);
+    a.rays = rays_dev; a.z = z_dev; a.out = raw_dev; a.S = S; a.tpr = (S + 31) / 32;
+    a.n_wtiles = (long long)n_rays * a.tpr;
+    a.stash_h = stash_h; a.stash_f = stash_f; a.stash_g = stash_g; a.stash_rows = (long long)n_rays * S;
+    return net->W == 256 ? launch<256, 0, true>(a, a.n_wtiles, st) : launch<128, 0, true>(a, a.n_wtiles, st);
 }
 
 int mlp_embedded_fp32(const mi_nerf_net* net, const void* packed_dev, const float* x_dev, int64_t n, float* out_dev,

@@ -261,6 +261,94 @@ __global__ __launch_bounds__(256) void composite_kernel(const float* __restrict_
     }
 }
 
+// exclusive SUFFIX sum across the 64 lanes (sum of the lanes above this one), Kogge-Stone on __shfl_down
+__device__ __forceinline__ float wave_excl_suffix_sum(float v, int lane) {
+    float inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const float o = __shfl_down(inc, d, 64);
+        if (lane + d < 64) inc += o;
+    }
+    const float e = __shfl_down(inc, 1, 64);
+    return lane == 63 ? 0.0f : e;
+}
+
+// ------------------------------------------------------------------------------------------------
+// alpha compositing, backward: d rgb_map [n,3] -> d raw [n,S,4]   (what autograd does for
+// nerf_process.py:89-140 when the loss reads rgb_map only, train.py:59-66; depths are constants:
+// the coarse ones carry no graph and the fine ones are detached at nerf_process.py:66).
+//   rgb_map = sum_i w_i c_i + 1 - sum_i w_i,  w_i = a_i T_i,  T_i = prod_{k<i} u_k,  u_k = 1 - a_k + 1e-10
+//   q_i := dL/dw_i = sum_ch G_ch (c_i,ch - 1)
+//   dL/da_i = q_i T_i - (sum_{k>i} q_k w_k) / u_i
+//   da_i/dsigma_i = dist_i exp(-relu(sigma_i) dist_i) for sigma_i > 0, else 0;  dc/draw = c (1 - c)
+// Same wave-per-ray decomposition as the forward kernel; the forward quantities are recomputed.
+// ------------------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restrict__ raw, const float* __restrict__ z,
+                                                             const float* __restrict__ rays, int ray_stride, long long n, int S,
+                                                             const float* __restrict__ d_rgb, float* __restrict__ d_raw) {
+    const int lane = threadIdx.x & 63;
+    const long long ray = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= n) return;
+    const float* dp = rays + ray * ray_stride + (ray_stride == 6 ? 3 : 0);
+    const float dx = dp[0], dy = dp[1], dz = dp[2];
+    const float dnorm = __builtin_sqrtf(dx * dx + dy * dy + dz * dz);
+    const float* zr = z + ray * S;
+    const f32x4* rr = (const f32x4*)(raw + ray * S * 4);
+    f32x4* out = (f32x4*)(d_raw + ray * S * 4);
+    const float Gr = d_rgb[ray * 3 + 0], Gg = d_rgb[ray * 3 + 1], Gb = d_rgb[ray * 3 + 2];
+
+    float alpha[C], dads[C], cr[C], cg[C], cb[C];
+    float local = 1.0f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const int s = lane * C + c;
+        const bool in = s < S;
+        const int sc = in ? s : S - 1;
+        const f32x4 v = rr[sc];
+        float dist = (s + 1 < S) ? (zr[s + 1] - zr[sc]) : 1e10f;
+        dist = dist * dnorm;
+        const float sig = __builtin_fmaxf(v[3], 0.0f);
+        const float e = expf(-sig * dist);
+        float a = 1.0f - e;
+        float ds = (v[3] > 0.0f) ? dist * e : 0.0f;
+        if (!in || S == 1) { a = 0.0f; ds = 0.0f; }
+        alpha[c] = a;
+        dads[c] = ds;
+        cr[c] = 1.0f / (1.0f + expf(-v[0]));
+        cg[c] = 1.0f / (1.0f + expf(-v[1]));
+        cb[c] = 1.0f / (1.0f + expf(-v[2]));
+        local *= in ? (1.0f - a + 1e-10f) : 1.0f;
+    }
+    float T = wave_excl_prod(local, lane);
+    float Tc[C], q[C], w[C];
+    float lsum = 0.0f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        Tc[c] = T;
+        w[c] = alpha[c] * T;
+        q[c] = Gr * (cr[c] - 1.0f) + Gg * (cg[c] - 1.0f) + Gb * (cb[c] - 1.0f);
+        lsum += q[c] * w[c];
+        T *= (1.0f - alpha[c] + 1e-10f);
+    }
+    float R = wave_excl_suffix_sum(lsum, lane);     // sum over the samples owned by higher lanes
+#pragma unroll
+    for (int c = C - 1; c >= 0; --c) {
+        const int s = lane * C + c;
+        const float u = 1.0f - alpha[c] + 1e-10f;
+        const float dLda = q[c] * Tc[c] - R / u;
+        R += q[c] * w[c];
+        if (s < S) {
+            f32x4 o;
+            o[0] = Gr * w[c] * cr[c] * (1.0f - cr[c]);
+            o[1] = Gg * w[c] * cg[c] * (1.0f - cg[c]);
+            o[2] = Gb * w[c] * cb[c] * (1.0f - cb[c]);
+            o[3] = dLda * dads[c];
+            out[s] = o;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // inverse-CDF sampling, one wavefront per ray.  cdf/bins live in this wave's LDS slice.
 // ------------------------------------------------------------------------------------------------
@@ -463,6 +551,22 @@ int stage_composite(const float* raw, const float* z, const float* rays, int ray
     else if (C <= 8) MN_COMP(8); else MN_COMP(16);
 #undef MN_COMP
     MN_LAUNCH_CHECK("composite_kernel");
+    return MI_NERF_OK;
+}
+
+int stage_composite_backward(const float* raw, const float* z, const float* rays, int ray_stride, int64_t n, int S,
+                             const float* d_rgb, float* d_raw, hipStream_t st) {
+    MN_CHECK_ARG(n >= 0 && S >= 1 && S <= 1024, "bad sizes (n=%lld S=%d)", (long long)n, S);
+    MN_CHECK_ARG(ray_stride == 3 || ray_stride == 6, "ray_stride must be 3 or 6");
+    if (n == 0) return MI_NERF_OK;
+    MN_CHECK_ARG(raw && z && rays && d_rgb && d_raw, "NULL pointer");
+    const dim3 grid(blocks_for(n, 4)), block(256);
+    const int C = (S + 63) / 64;
+#define MN_COMPB(CC) hipLaunchKernelGGL(composite_bwd_kernel<CC>, grid, block, 0, st, raw, z, rays, ray_stride, (long long)n, S, d_rgb, d_raw)
+    if (C == 1) MN_COMPB(1); else if (C == 2) MN_COMPB(2); else if (C == 3) MN_COMPB(3); else if (C == 4) MN_COMPB(4);
+    else if (C <= 8) MN_COMPB(8); else MN_COMPB(16);
+#undef MN_COMPB
+    MN_LAUNCH_CHECK("composite_bwd_kernel");
     return MI_NERF_OK;
 }
 

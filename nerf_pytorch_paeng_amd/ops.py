@@ -231,6 +231,22 @@ def composite(raw: torch.Tensor, z: torch.Tensor, rays_or_d: torch.Tensor, want_
     return rgb, disp, acc, wts, depth
 
 
+def composite_backward(raw: torch.Tensor, z: torch.Tensor, rays_or_d: torch.Tensor, d_rgb: torch.Tensor) -> torch.Tensor:
+    """d rgb_map [n,3] -> d raw [n,S,4]: what autograd yields for nerf_process.py:89-140 when the loss reads rgb_map."""
+    n, S = z.shape
+    if tuple(raw.shape) != (n, S, 4) or tuple(d_rgb.shape) != (n, 3):
+        raise MiNerfError(f"raw must be {(n, S, 4)} and d_rgb {(n, 3)}, got {tuple(raw.shape)} / {tuple(d_rgb.shape)}")
+    stride = rays_or_d.shape[-1]
+    if tuple(rays_or_d.shape) != (n, stride) or stride not in (3, 6):
+        raise MiNerfError("rays must be [n,6] or rays_d [n,3]")
+    d_raw = torch.empty(n, S, 4, dtype=torch.float32, device=z.device)
+    with _guard(z.device):
+        check(lib().mi_nerf_composite_backward(dev_ptr(raw, "raw", align=16), dev_ptr(z, "z"), dev_ptr(rays_or_d, "rays"), stride, n, S,
+                                               dev_ptr(d_rgb, "d_rgb"), dev_ptr(d_raw, "d_raw", align=16), stream_ptr(z.device)),
+              "mi_nerf_composite_backward")
+    return d_raw
+
+
 # ------------------------------------------------------------------------------------------------
 # fused render
 # ------------------------------------------------------------------------------------------------
