@@ -169,6 +169,37 @@ int mi_nerf_render_workspace_layout(const mi_nerf_render_cfg* cfg, int64_t n_ray
 int mi_nerf_composite_backward(const float* raw_dev, const float* z_dev, const float* rays_dev, int ray_stride,
                                int64_t n, int S, const float* d_rgb_dev, float* d_raw_dev, void* stream);
 
+/* Flat parameter vector of one NeRFModule, in module.parameters() order of model/NeRF.py:24-30:
+ * linear_x[0..D).{weight,bias}, linear_d.{weight,bias}, linear_feat, linear_density, linear_color
+ * (each weight [out,in] row-major).  Gradients come back in the same order. */
+size_t mi_nerf_param_count(const mi_nerf_net* net);
+
+/* Backward-data blob: the transposed weights in the order the backward chain consumes them (host packer). */
+size_t mi_nerf_packed_bytes_bwd(const mi_nerf_net* net);
+int mi_nerf_pack_weights_bwd(const mi_nerf_net* net, const mi_nerf_params* params, void* host_blob, size_t blob_bytes);
+/* Device-side re-pack (training re-packs after every optimizer.step(), train.py:70): a gather map, built once on
+ * the host, from the flat parameter vector to a blob.  kind 0: forward blob (mi_nerf_packed_bytes), 1: backward-data
+ * blob (mi_nerf_packed_bytes_bwd).  map_len = blob bytes / 4 entries; entry = 1 + flat index, 0 = constant zero. */
+int mi_nerf_pack_map(const mi_nerf_net* net, int kind, int32_t* map_host, size_t map_len);
+int mi_nerf_pack_apply(const int32_t* map_dev, const float* flat_params_dev, size_t blob_bytes, void* blob_dev, void* stream);
+
+/* Activation stash written by the training forward and the scratch the backward needs (byte offsets). */
+typedef struct mi_nerf_train_layout {
+    size_t stash_h, stash_f, stash_g, stash_bytes;               /* [D][P][W], [P][W], [P][W/2] post-activation rows */
+    size_t delta_h, delta_f, delta_d, emb, partial, work_bytes;  /* pre-activation gradients, encoded inputs, wgrad partials */
+} mi_nerf_train_layout;
+int mi_nerf_train_layout_query(const mi_nerf_net* net, int64_t n_pts, mi_nerf_train_layout* out);
+
+/* Training forward: mi_nerf_mlp_rays that also keeps every layer's activations (model/NeRF.py:33-52 with the
+ * autograd graph the reference builds implicitly).  stash: mi_nerf_train_layout.stash_bytes for n_rays*S points. */
+int mi_nerf_mlp_rays_train(const mi_nerf_net* net, const void* packed_dev, const float* rays_dev, const float* z_dev,
+                           int64_t n_rays, int S, float* raw_dev, void* stash_dev, size_t stash_bytes, void* stream);
+/* Backward of the above: d_raw [n_rays*S, 4] -> grads [mi_nerf_param_count] (overwritten, not accumulated).
+ * stage 0: full backward; 1: backward-data only (per-layer deltas left in work, for staged parity checks). */
+int mi_nerf_mlp_backward(const mi_nerf_net* net, const void* packed_dev, const void* packed_bwd_dev, const float* rays_dev,
+                         const float* z_dev, int64_t n_rays, int S, const float* d_raw_dev, const void* stash_dev,
+                         void* work_dev, size_t work_bytes, float* grads_dev, int stage, void* stream);
+
 /* Timing hook used by bench.py: average device time (ms) of `iters` back-to-back launches of the fused MLP
  * kernel on `stream`, measured with hipEvents recorded on that same stream (torch.cuda.Event only sees
  * torch's current stream).  Synchronises the stream. */

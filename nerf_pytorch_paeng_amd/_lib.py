@@ -42,6 +42,11 @@ class WorkspaceLayout(C.Structure):   # mi_nerf_workspace_layout
                 ("raw_f", C.c_size_t), ("total", C.c_size_t)]
 
 
+class TrainLayout(C.Structure):       # mi_nerf_train_layout
+    _fields_ = [(n, C.c_size_t) for n in ("stash_h", "stash_f", "stash_g", "stash_bytes", "delta_h", "delta_f", "delta_d", "emb",
+                                          "partial", "work_bytes")]
+
+
 _P, _I, _I64, _F, _U32, _SZ = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32, C.c_size_t
 _NETP = C.POINTER(Net)
 _CFGP = C.POINTER(RenderCfg)
@@ -71,6 +76,14 @@ SIGNATURES = {
     "mi_nerf_render_rays": (_I, [_NETP, _P, _P, _CFGP, _P, _I64, _P, _P, _P, _SZ, _P, _P, _P, _P, _P]),
     "mi_nerf_render_workspace_layout": (_I, [_CFGP, _I64, C.POINTER(WorkspaceLayout)]),
     "mi_nerf_composite_backward": (_I, [_P, _P, _P, _I, _I64, _I, _P, _P, _P]),
+    "mi_nerf_param_count": (_SZ, [_NETP]),
+    "mi_nerf_packed_bytes_bwd": (_SZ, [_NETP]),
+    "mi_nerf_pack_weights_bwd": (_I, [_NETP, C.POINTER(Params), _P, _SZ]),
+    "mi_nerf_pack_map": (_I, [_NETP, _I, _P, _SZ]),
+    "mi_nerf_pack_apply": (_I, [_P, _P, _SZ, _P, _P]),
+    "mi_nerf_train_layout_query": (_I, [_NETP, _I64, C.POINTER(TrainLayout)]),
+    "mi_nerf_mlp_rays_train": (_I, [_NETP, _P, _P, _P, _I64, _I, _P, _P, _SZ, _P]),
+    "mi_nerf_mlp_backward": (_I, [_NETP, _P, _P, _P, _P, _I64, _I, _P, _P, _P, _SZ, _P, _I, _P]),
     "mi_nerf_time_mlp_rays": (_I, [_NETP, _P, _P, _P, _I64, _I, _P, _I, _I, C.POINTER(_F), _P]),
     "mi_nerf_selftest_mfma": (_I, [_P]),
 }

@@ -26,6 +26,14 @@ size_t packed_bytes_bf16(const mi_nerf_net*);
 int mlp_rays_fp32(const mi_nerf_net*, const void*, const float*, const float*, int64_t, int, float*, hipStream_t);
 int mlp_embedded_fp32(const mi_nerf_net*, const void*, const float*, int64_t, float*, hipStream_t);
 int mlp_rays_bf16(const mi_nerf_net*, const void*, const float*, const float*, int64_t, int, float*, hipStream_t);
+int mlp_rays_fp32_stash(const mi_nerf_net*, const void*, const float*, const float*, int64_t, int, float*, float*, float*, float*, hipStream_t);
+int mlp_backward_fp32(const mi_nerf_net*, const void*, const void*, const float*, const float*, int64_t, int, const float*, const void*, void*,
+                      size_t, float*, int, hipStream_t);
+int train_layout(const mi_nerf_net*, int64_t, mi_nerf_train_layout*);
+int pack_apply(const int32_t*, const float*, size_t, void*, hipStream_t);
+int pack_bwd_fp32(const mi_nerf_net*, const mi_nerf_params*, void*, size_t);
+size_t packed_bytes_bwd(const mi_nerf_net*);
+int pack_map(const mi_nerf_net*, int, int32_t*, size_t);
 int stage_make_o_d(int, int, const float*, const float*, int, int, float*, float*, hipStream_t);
 int stage_make_o_d_pixels(int, int, const float*, const float*, const int64_t*, int64_t, float*, float*, hipStream_t);
 int stage_ndc(int, int, float, float, const float*, int64_t, const float*, int64_t, int64_t, float*, float*, hipStream_t);
@@ -167,6 +175,48 @@ int mi_nerf_composite(const float* raw, const float* z, const float* rays, int r
 int mi_nerf_composite_backward(const float* raw, const float* z, const float* rays, int ray_stride, int64_t n, int S,
                                const float* d_rgb, float* d_raw, void* st) {
     return stage_composite_backward(raw, z, rays, ray_stride, n, S, d_rgb, d_raw, (hipStream_t)st);
+}
+
+size_t mi_nerf_param_count(const mi_nerf_net* net) {
+    if (check_net_basic(net)) return 0;
+    return make_param_offsets(net->D, net->W, net->skip, net->L_x, net->L_d).total;
+}
+size_t mi_nerf_packed_bytes_bwd(const mi_nerf_net* net) {
+    if (check_net_basic(net)) return 0;
+    return packed_bytes_bwd(net);
+}
+int mi_nerf_pack_weights_bwd(const mi_nerf_net* net, const mi_nerf_params* params, void* host_blob, size_t blob_bytes) {
+    if (int rc = check_net_basic(net)) return rc;
+    MN_CHECK_ARG(params && host_blob, "NULL params/blob");
+    return pack_bwd_fp32(net, params, host_blob, blob_bytes);
+}
+int mi_nerf_pack_map(const mi_nerf_net* net, int kind, int32_t* map_host, size_t map_len) {
+    if (int rc = check_net_basic(net)) return rc;
+    return pack_map(net, kind, map_host, map_len);
+}
+int mi_nerf_pack_apply(const int32_t* map_dev, const float* flat_dev, size_t blob_bytes, void* blob_dev, void* st) {
+    return pack_apply(map_dev, flat_dev, blob_bytes, blob_dev, (hipStream_t)st);
+}
+int mi_nerf_train_layout_query(const mi_nerf_net* net, int64_t n_pts, mi_nerf_train_layout* out) {
+    if (int rc = check_net_basic(net)) return rc;
+    return train_layout(net, n_pts, out);
+}
+int mi_nerf_mlp_rays_train(const mi_nerf_net* net, const void* packed, const float* rays, const float* z, int64_t n_rays, int S,
+                           float* raw, void* stash, size_t stash_bytes, void* st) {
+    if (int rc = check_net_basic(net)) return rc;
+    MN_CHECK_ARG(n_rays >= 0 && S >= 1, "bad sizes n_rays=%lld S=%d", (long long)n_rays, S);
+    mi_nerf_train_layout L;
+    if (int rc = train_layout(net, n_rays * S, &L)) return rc;
+    if (n_rays == 0) return MI_NERF_OK;
+    MN_CHECK_ARG(stash != nullptr && stash_bytes >= L.stash_bytes, "stash too small: %zu < %zu", stash_bytes, L.stash_bytes);
+    return mlp_rays_fp32_stash(net, packed, rays, z, n_rays, S, raw, (float*)((char*)stash + L.stash_h), (float*)((char*)stash + L.stash_f),
+                               (float*)((char*)stash + L.stash_g), (hipStream_t)st);
+}
+int mi_nerf_mlp_backward(const mi_nerf_net* net, const void* packed, const void* packed_bwd, const float* rays, const float* z,
+                         int64_t n_rays, int S, const float* d_raw, const void* stash, void* work, size_t work_bytes, float* grads,
+                         int stage, void* st) {
+    if (int rc = check_net_basic(net)) return rc;
+    return mlp_backward_fp32(net, packed, packed_bwd, rays, z, n_rays, S, d_raw, stash, work, work_bytes, grads, stage, (hipStream_t)st);
 }
 
 size_t mi_nerf_render_workspace_bytes(const mi_nerf_render_cfg* cfg, int64_t n_rays) {

@@ -83,4 +83,46 @@ inline BlobLayout make_layout(int D, int W, int skip, int L_x, int L_d) {
     return b;
 }
 
+// ---------------------------------------------------------------------------------------------
+// training path
+// ---------------------------------------------------------------------------------------------
+// Flat parameter vector of one NeRFModule in module.parameters() order (model/NeRF.py:24-30):
+// linear_x[0..D).{weight,bias}, linear_d, linear_feat, linear_density, linear_color.  Offsets in floats.
+struct ParamOffsets {
+    uint32_t w_x[16], b_x[16];
+    int in_l[16];                 // input width of trunk layer l
+    uint32_t w_d, b_d, w_feat, b_feat, w_dens, b_dens, w_color, b_color;
+    uint32_t total;
+};
+
+inline ParamOffsets make_param_offsets(int D, int W, int skip, int L_x, int L_d) {
+    ParamOffsets p{};
+    const int in_x = 3 + 6 * L_x, in_d = 3 + 6 * L_d;
+    uint32_t f = 0;
+    for (int l = 0; l < D; ++l) {
+        p.in_l[l] = (l == 0) ? in_x : ((skip >= 0 && l == skip + 1) ? W + in_x : W);
+        p.w_x[l] = f; f += (uint32_t)W * p.in_l[l];
+        p.b_x[l] = f; f += W;
+    }
+    p.w_d = f;     f += (uint32_t)(W / 2) * (W + in_d);
+    p.b_d = f;     f += W / 2;
+    p.w_feat = f;  f += (uint32_t)W * W;
+    p.b_feat = f;  f += W;
+    p.w_dens = f;  f += W;
+    p.b_dens = f;  f += 1;
+    p.w_color = f; f += 3 * (W / 2);
+    p.b_color = f; f += 3;
+    p.total = f;
+    return p;
+}
+
+// Backward-data stream (mlp_train.hip): the TRANSPOSED weights as MFMA A operands, in the order the chain
+// d_hidden -> linear_d^T (feature block) -> linear_feat^T -> linear_x[D-1]^T ... linear_x[1]^T consumes them.
+// Blob = header | stream; the side tables of the forward blob are reused.
+inline uint32_t bwd_stream_bytes(int D, int W) {
+    const uint32_t NT = W / 32;
+    const uint32_t quads = (uint32_t)(W / 16) * NT + (uint32_t)D * (uint32_t)(W / 8) * NT;
+    return round_up_u32(quads, SLOT_QUADS) * QUAD_BYTES;
+}
+
 }  // namespace minerf

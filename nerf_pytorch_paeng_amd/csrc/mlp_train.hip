@@ -1,0 +1,450 @@
+// mlp_train.hip -- backward pass of the NeRF MLP on fp32 MFMA (gfx950): what `loss.backward()` does for
+// model/NeRF.py:33-52 inside train.py:53-70.
+//
+// Three kernels, all fed from the row-major activation stash the training forward keeps (mlp_fp32.hip, STASH):
+//   * mlp_dgrad_kernel   backward-data chain.  Same register-resident design as the forward kernel: a wave owns 32
+//                        points, the gradient w.r.t. a layer's output sits in the MFMA accumulators, is masked by the
+//                        stashed post-ReLU activation (ReLU') and is directly the B operand of the next (transposed)
+//                        GEMM.  The TRANSPOSED weights stream through the same LDS ring (pack.cpp: pack_bwd_fp32).
+//                        Writes the pre-activation gradient ("delta") of every layer row-major.
+//   * wgrad_kernel       dW[m][n] = sum_p delta[p][m] * input[p][n]: the contraction runs over POINTS, so both MFMA
+//                        operands are plain row-major reads (lane = feature, k = point).  One workgroup accumulates a
+//                        whole 256x256 block (16 accumulator tiles per wave) over a slice of the points; bias
+//                        gradients are column sums of the same operand, accumulated on the VALU under the MFMAs.
+//   * reduce_partial_kernel  deterministic slice reduction into the parameter-gradient vector.
+// Nothing is differentiated w.r.t. the sample positions or view directions: the reference's only trainable
+// tensors are the MLP parameters (train.py:149-152).
+#include <vector>
+#include "mlp_core.h"
+
+namespace minerf {
+
+int stage_embed(const float*, const float*, int64_t, int, int, int, float*, hipStream_t);
+
+// ---------------------------------------------------------------------------------------------
+// backward data
+// ---------------------------------------------------------------------------------------------
+struct DgradArgs {
+    const char* stream;       // backward blob + HEADER_BYTES
+    unsigned stream_bytes;
+    const float* side;        // forward blob's side tables (colour / density head weights)
+    unsigned side_floats, o_dens_w, o_color_w;
+    const float* d_raw;       // [P][4]  dL/d(rgb_raw, density_raw)
+    const float* stash_h;     // [D][P][W]
+    const float* stash_g;     // [P][W/2]
+    float* delta_h;           // [D][P][W]   dL/d(pre-activation of trunk layer l)
+    float* delta_f;           // [P][W]      dL/d(linear_feat output)
+    float* delta_d;           // [P][W/2]    dL/d(pre-activation of linear_d)
+    long long P;
+    long long n_wtiles;
+    int D;
+};
+
+template <int NT>
+__device__ __forceinline__ void acc_zero(f32x16 (&acc)[8]) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+}
+
+template <int W>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void mlp_dgrad_kernel(const DgradArgs a) {
+    constexpr int NT = W / 32;
+    constexpr int HN = W / 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* side = (float*)(smem + RING_BYTES);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 31, hh = lane >> 5;
+
+    for (unsigned i = tid * 4; i < a.side_floats; i += 256 * 4) *(f32x4*)(side + i) = *(const f32x4*)(a.side + i);
+
+    const long long n_wg_tiles = (a.n_wtiles + 3) >> 2;
+    if ((long long)blockIdx.x >= n_wg_tiles) return;
+
+    WRing ring;
+    ring.sbase = a.stream + wave * (4 * QUAD_BYTES);
+    ring.voff = lane * 16;
+    ring.fetch_off = 0;
+    ring.stream_bytes = a.stream_bytes;
+    ring.lds_lo = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + wave * (4 * QUAD_BYTES);
+    ring.lds_hi = ring.lds_lo + RING_BYTES;
+    ring.fetch_lds = ring.lds_lo;
+    ring.read_slot = NSLOT - 1;
+#ifdef MN_DIAG
+    ring.dlog = nullptr; ring.dcnt = 0;
+#endif
+#pragma unroll
+    for (int sl = 0; sl < 3; ++sl) {
+        if (sl) ring_next_fetch(ring);
+        ring_dma<0>(ring); ring_dma<1>(ring); ring_dma<2>(ring); ring_dma<3>(ring);
+    }
+
+    f32x16 acc[8];
+    f32x4 aq[8];
+    float h[HN];
+    ring_advance(ring);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) aq[t] = ring_read(smem, ring, lane, t);
+
+    const float* cw = side + a.o_color_w;
+    const float* dw = side + a.o_dens_w;
+    for (long long wgt = blockIdx.x; wgt < n_wg_tiles; wgt += gridDim.x) {
+        long long wt = wgt * 4 + wave;
+        const bool wave_active = wt < a.n_wtiles;
+        if (!wave_active) wt = a.n_wtiles - 1;
+        const long long p0 = wt * 32 + col;
+        const bool valid = wave_active && p0 < a.P;
+        const long long idx = p0 < a.P ? p0 : a.P - 1;
+        f32x4 dr = *(const f32x4*)(a.d_raw + idx * 4);
+        if (!valid) { dr[0] = 0.f; dr[1] = 0.f; dr[2] = 0.f; dr[3] = 0.f; }
+
+        // ---- colour head^T (VALU, 3 inputs) and ReLU' of linear_d ----
+        float h2[HN / 2];
+        {
+            const float* grow = a.stash_g + idx * (W / 2) + 4 * hh;
+#pragma unroll
+            for (int q = 0; q < HN / 8; ++q) {
+                const f32x4 w0 = *(const f32x4*)(cw + 8 * q + 4 * hh);
+                const f32x4 w1 = *(const f32x4*)(cw + W / 2 + 8 * q + 4 * hh);
+                const f32x4 w2 = *(const f32x4*)(cw + W + 8 * q + 4 * hh);
+                const f32x4 g = *(const f32x4*)(grow + 8 * q);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = dr[0] * w0[j];
+                    v = __builtin_fmaf(dr[1], w1[j], v);
+                    v = __builtin_fmaf(dr[2], w2[j], v);
+                    h2[4 * q + j] = g[j] > 0.0f ? v : 0.0f;
+                }
+            }
+        }
+        store_rows<NT / 2>(h2, a.delta_d + idx * (W / 2) + 4 * hh, valid);
+        // ---- linear_d^T, feature block: d feature = Wd[:, :W]^T delta_d ----
+        acc_zero<NT>(acc);
+        gemm_part<NT, HN / 2, NT>(acc, h2, aq, smem, ring, lane);
+        acc_to_b<NT, false>(acc, h);
+        store_rows<NT>(h, a.delta_f + idx * W + 4 * hh, valid);
+        // ---- linear_feat^T (+ density head^T, rank 1) -> gradient of the trunk output ----
+        acc_zero<NT>(acc);
+        gemm_part<NT, HN, NT>(acc, h, aq, smem, ring, lane);
+        // ---- trunk, last layer first ----
+#pragma unroll 1
+        for (int l = a.D - 1;; --l) {
+            const float* hrow = a.stash_h + ((long long)l * a.P + idx) * W + 4 * hh;
+            const float ds = (l == a.D - 1) ? dr[3] : 0.0f;
+#pragma unroll
+            for (int q = 0; q < 4 * NT; ++q) {
+                const f32x4 hv = *(const f32x4*)(hrow + 8 * q);
+                const f32x4 wv = *(const f32x4*)(dw + 8 * q + 4 * hh);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v = __builtin_fmaf(wv[j], ds, acc[q >> 2][4 * (q & 3) + j]);
+                    h[4 * q + j] = hv[j] > 0.0f ? v : 0.0f;                       // ReLU'
+                }
+            }
+            store_rows<NT>(h, a.delta_h + ((long long)l * a.P + idx) * W + 4 * hh, valid);
+            if (l == 0) break;
+            acc_zero<NT>(acc);
+            gemm_part<NT, HN, NT>(acc, h, aq, smem, ring, lane);                  // W_l[:, h-block]^T delta_l
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward weights
+// ---------------------------------------------------------------------------------------------
+struct WgradArgs {
+    const float* dlt; int ldd; int M;     // delta [P, ldd]: columns [0, M) of the pointer
+    const float* x;   int ldx; int N;     // layer input [P, ldx]: columns [0, N)
+    long long P;
+    int pps;                              // points per slice (multiple of 16)
+    float* partial;                       // [slices][Mp][Np]
+    float* bpartial;                      // [slices][Mp] column sums of delta, or NULL
+    int Mp, Np;
+};
+
+// Workgroup = 2x2 waves, each wave TM x TN tiles of 32x32: block (64 TM) x (64 TN) of dW.
+template <int TM, int TN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void wgrad_kernel(const WgradArgs a) {
+    constexpr int U = 6;                  // k-steps (2 points each) per software-pipeline stage
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = lane & 31, kh = lane >> 5;
+    const int m0 = blockIdx.y * (64 * TM) + (wave >> 1) * (32 * TM);
+    const int n0 = blockIdx.z * (64 * TN) + (wave & 1) * (32 * TN);
+    const long long pb = (long long)blockIdx.x * a.pps;
+    const long long pe = (pb + a.pps < a.P) ? pb + a.pps : a.P;
+
+    const float* ap[TM]; bool aok[TM];
+    const float* bp[TN]; bool bok[TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) { const int c = m0 + 32 * tm + i; aok[tm] = c < a.M; ap[tm] = a.dlt + (aok[tm] ? c : a.M - 1); }
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) { const int c = n0 + 32 * tn + i; bok[tn] = c < a.N; bp[tn] = a.x + (bok[tn] ? c : a.N - 1); }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.0f;
+    float bsum[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) bsum[tm] = 0.0f;
+
+    float ca[U][TM], cb[U][TN], na[U][TM], nb[U][TN];
+    auto load = [&](long long p, float (&A)[U][TM], float (&B)[U][TN]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long row = p + 2 * u + kh;
+            const bool ok = row < pe;
+            const long long r = ok ? row : pe - 1;
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) { const float v = ap[tm][r * a.ldd]; A[u][tm] = (ok && aok[tm]) ? v : 0.0f; }
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) { const float v = bp[tn][r * a.ldx]; B[u][tn] = (ok && bok[tn]) ? v : 0.0f; }
+        }
+    };
+    load(pb, ca, cb);
+    for (long long p = pb; p < pe; p += 2 * U) {
+        load(p + 2 * U, na, nb);          // past the slice end: clamped address, zero value
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                bsum[tm] += ca[u][tm];
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[u][tm], cb[u][tn], acc[tm][tn], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) ca[u][tm] = na[u][tm];
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) cb[u][tn] = nb[u][tn];
+        }
+    }
+    // D[i'][j]: row i' = (r&3) + 8*(r>>2) + 4*kh (delta feature), column j = lane & 31 (input feature)
+    float* out = a.partial + (size_t)blockIdx.x * a.Mp * a.Np;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + 32 * tm + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                out[(size_t)m * a.Np + n0 + 32 * tn + i] = acc[tm][tn][r];
+            }
+    if (a.bpartial && blockIdx.z == 0 && (wave & 1) == 0) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            const float s = bsum[tm] + __shfl_xor(bsum[tm], 32, 64);     // even + odd points of every k-step
+            if (kh == 0) a.bpartial[(size_t)blockIdx.x * a.Mp + m0 + 32 * tm + i] = s;
+        }
+    }
+}
+
+// out[m*ldo + n] = sum_s partial[s][m][n]  (m < M, n < N);  bias[m] = sum_s bpartial[s][m]
+__global__ __launch_bounds__(256) void reduce_partial_kernel(const float* __restrict__ partial, const float* __restrict__ bpartial,
+                                                              int slices, int Mp, int Np, int M, int N, float* __restrict__ out, int ldo,
+                                                              float* __restrict__ bias) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx < M * N) {
+        const int m = idx / N, n = idx - m * N;
+        const float* p = partial + (size_t)m * Np + n;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int s = 0;
+        for (; s + 4 <= slices; s += 4) {
+            s0 += p[(size_t)(s + 0) * Mp * Np]; s1 += p[(size_t)(s + 1) * Mp * Np];
+            s2 += p[(size_t)(s + 2) * Mp * Np]; s3 += p[(size_t)(s + 3) * Mp * Np];
+        }
+        for (; s < slices; ++s) s0 += p[(size_t)s * Mp * Np];
+        out[(size_t)m * ldo + n] = (s0 + s1) + (s2 + s3);
+    } else if (bias && idx < M * N + M) {
+        const int m = idx - M * N;
+        float s0 = 0.f;
+        for (int s = 0; s < slices; ++s) s0 += bpartial[(size_t)s * Mp + m];
+        bias[m] = s0;
+    }
+}
+
+// blob[i] = map[i] ? flat[map[i] - 1] : 0      (device-side re-pack after an optimiser step; map from pack_map)
+__global__ __launch_bounds__(256) void pack_apply_kernel(const int32_t* __restrict__ map, const float* __restrict__ flat, long long n,
+                                                          float* __restrict__ blob) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int32_t m = map[i];
+    blob[i] = m > 0 ? flat[m - 1] : 0.0f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static int num_cus_t() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
+static inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+constexpr size_t WGRAD_PARTIAL_FLOATS = (size_t)256 * 256 * 256 + (size_t)256 * 256;   // 256 slices of a 256x256 block + bias rows
+
+int train_layout(const mi_nerf_net* net, int64_t P, mi_nerf_train_layout* L) {
+    MN_CHECK_ARG(net && L, "NULL net/layout");
+    MN_CHECK_ARG(net->W == 256 || net->W == 128, "unsupported width W=%d", net->W);
+    MN_CHECK_ARG(net->D >= 2 && net->D <= 16, "unsupported depth D=%d", net->D);
+    MN_CHECK_ARG(P >= 0, "bad point count %lld", (long long)P);
+    const size_t p = (size_t)P, W = (size_t)net->W, D = (size_t)net->D;
+    const size_t in_all = (size_t)(3 + 6 * net->L_x) + (size_t)(3 + 6 * net->L_d);
+    size_t off = 0;
+    L->stash_h = off; off += al256(D * p * W * 4);
+    L->stash_f = off; off += al256(p * W * 4);
+    L->stash_g = off; off += al256(p * (W / 2) * 4);
+    L->stash_bytes = off;
+    off = 0;
+    L->delta_h = off; off += al256(D * p * W * 4);
+    L->delta_f = off; off += al256(p * W * 4);
+    L->delta_d = off; off += al256(p * (W / 2) * 4);
+    L->emb = off;     off += al256(p * in_all * 4);
+    L->partial = off; off += al256(WGRAD_PARTIAL_FLOATS * 4);
+    L->work_bytes = off;
+    return MI_NERF_OK;
+}
+
+// one dW (+ optional bias) = delta^T x input, slice partials reduced into `out`
+static int run_wgrad(const float* dlt, int ldd, int M, const float* x, int ldx, int N, long long P, float* out, int ldo, float* bias,
+                     float* partial, hipStream_t st) {
+    WgradArgs a{};
+    a.dlt = dlt; a.ldd = ldd; a.M = M; a.x = x; a.ldx = ldx; a.N = N; a.P = P;
+    const bool big = (M > 64 && N > 64);
+    const int bm = big ? 256 : 64, bn = big ? 256 : 64;
+    const int by = (M + bm - 1) / bm, bz = (N + bn - 1) / bn;
+    a.Mp = by * bm; a.Np = bz * bn;
+    int slices = num_cus_t() / (by * bz);
+    if (slices < 1) slices = 1;
+    if (slices > 256) slices = 256;
+    long long pps = (P + slices - 1) / slices;
+    pps = (pps + 15) / 16 * 16;
+    slices = (int)((P + pps - 1) / pps);
+    MN_CHECK_ARG((size_t)slices * a.Mp * a.Np + (size_t)slices * a.Mp <= WGRAD_PARTIAL_FLOATS, "internal: wgrad partial buffer too small");
+    a.pps = (int)pps;
+    a.partial = partial;
+    a.bpartial = bias ? partial + (size_t)slices * a.Mp * a.Np : nullptr;
+    const dim3 grid(slices, by, bz);
+    if (big) hipLaunchKernelGGL((wgrad_kernel<4, 4>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((wgrad_kernel<1, 1>), grid, dim3(256), 0, st, a);
+    MN_LAUNCH_CHECK("wgrad_kernel");
+    const int total = M * N + (bias ? M : 0);
+    hipLaunchKernelGGL(reduce_partial_kernel, dim3((total + 255) / 256), dim3(256), 0, st, (const float*)partial, (const float*)a.bpartial,
+                       slices, a.Mp, a.Np, M, N, out, ldo, bias);
+    MN_LAUNCH_CHECK("reduce_partial_kernel");
+    return MI_NERF_OK;
+}
+
+template <int W>
+static int launch_dgrad(const DgradArgs& a, hipStream_t st) {
+    const size_t lds = RING_BYTES + (size_t)a.side_floats * 4;
+    MN_CHECK_ARG(lds <= 160 * 1024, "LDS budget exceeded: %zu bytes", lds);
+    auto kern = mlp_dgrad_kernel<W>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        MN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    const long long n_wg = (a.n_wtiles + 3) / 4;
+    const int grid = (int)(n_wg < (long long)num_cus_t() ? n_wg : (long long)num_cus_t());
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
+    MN_LAUNCH_CHECK("mlp_dgrad_kernel");
+    return MI_NERF_OK;
+}
+
+// d_raw [P,4] -> flat parameter gradient (ParamOffsets order).  stash: written by mlp_rays_fp32_stash for the same
+// rays/z; work: scratch of train_layout().work_bytes.  stage 0: everything; 1: stop after the backward-data kernel
+// (deltas stay in `work` for inspection).
+int mlp_backward_fp32(const mi_nerf_net* net, const void* packed_fwd, const void* packed_bwd, const float* rays, const float* z,
+                      int64_t n_rays, int S, const float* d_raw, const void* stash, void* work, size_t work_bytes, float* grads,
+                      int stage, hipStream_t st) {
+    MN_CHECK_ARG(net != nullptr, "net is NULL");
+    MN_CHECK_ARG(net->L_x == 10 && net->L_d == 4, "unsupported encoding L_x=%d L_d=%d", net->L_x, net->L_d);
+    MN_CHECK_ARG(net->skip >= -1, "bad skip=%d", net->skip);
+    MN_CHECK_ARG(n_rays >= 0 && S >= 1, "bad sizes n_rays=%lld S=%d", (long long)n_rays, S);
+    const long long P = (long long)n_rays * S;
+    mi_nerf_train_layout L;
+    if (int rc = train_layout(net, P, &L)) return rc;
+    if (P == 0) return MI_NERF_OK;
+    MN_CHECK_ARG(packed_fwd && packed_bwd && rays && z && d_raw && stash && work && grads, "NULL device pointer");
+    MN_CHECK_ARG(work_bytes >= L.work_bytes, "workspace too small: %zu < %zu", work_bytes, L.work_bytes);
+    const int D = net->D, W = net->W;
+    const int in_x = 3 + 6 * net->L_x, in_d = 3 + 6 * net->L_d, in_all = in_x + in_d;
+    const BlobLayout BL = make_layout(D, W, net->skip, net->L_x, net->L_d);
+    const ParamOffsets po = make_param_offsets(D, W, net->skip, net->L_x, net->L_d);
+    const float* stash_h = (const float*)((const char*)stash + L.stash_h);
+    const float* stash_f = (const float*)((const char*)stash + L.stash_f);
+    const float* stash_g = (const float*)((const char*)stash + L.stash_g);
+    float* delta_h = (float*)((char*)work + L.delta_h);
+    float* delta_f = (float*)((char*)work + L.delta_f);
+    float* delta_d = (float*)((char*)work + L.delta_d);
+    float* emb = (float*)((char*)work + L.emb);
+    float* partial = (float*)((char*)work + L.partial);
+
+    DgradArgs a{};
+    a.stream = (const char*)packed_bwd + HEADER_BYTES;
+    a.stream_bytes = bwd_stream_bytes(D, W);
+    a.side = (const float*)((const char*)packed_fwd + BL.side_off);
+    a.side_floats = BL.side_floats; a.o_dens_w = BL.dens_w; a.o_color_w = BL.color_w;
+    a.d_raw = d_raw; a.stash_h = stash_h; a.stash_g = stash_g;
+    a.delta_h = delta_h; a.delta_f = delta_f; a.delta_d = delta_d;
+    a.P = P; a.n_wtiles = (P + 31) / 32; a.D = D;
+    if (int rc = (W == 256 ? launch_dgrad<256>(a, st) : launch_dgrad<128>(a, st))) return rc;
+    if (stage == 1) return MI_NERF_OK;
+
+    // layer inputs gamma(x), gamma(d) as rows (nerf_process.py:69-85)
+    if (int rc = stage_embed(rays, z, n_rays, S, net->L_x, net->L_d, emb, st)) return rc;
+    const size_t PW = (size_t)P * W;
+    // trunk
+    if (int rc = run_wgrad(delta_h, W, W, emb, in_all, in_x, P, grads + po.w_x[0], in_x, grads + po.b_x[0], partial, st)) return rc;
+    for (int l = 1; l < D; ++l) {
+        const bool cat = po.in_l[l] != W;
+        const float* dl = delta_h + (size_t)l * PW;
+        float* gw = grads + po.w_x[l];
+        if (cat)
+            if (int rc = run_wgrad(dl, W, W, emb, in_all, in_x, P, gw, po.in_l[l], nullptr, partial, st)) return rc;   // [gamma(x), h]
+        if (int rc = run_wgrad(dl, W, W, stash_h + (size_t)(l - 1) * PW, W, W, P, gw + (cat ? in_x : 0), po.in_l[l], grads + po.b_x[l],
+                               partial, st)) return rc;
+    }
+    const float* h_last = stash_h + (size_t)(D - 1) * PW;
+    // heads
+    if (int rc = run_wgrad(delta_f, W, W, h_last, W, W, P, grads + po.w_feat, W, grads + po.b_feat, partial, st)) return rc;
+    if (int rc = run_wgrad(d_raw + 3, 4, 1, h_last, W, W, P, grads + po.w_dens, W, grads + po.b_dens, partial, st)) return rc;
+    if (int rc = run_wgrad(delta_d, W / 2, W / 2, stash_f, W, W, P, grads + po.w_d, W + in_d, grads + po.b_d, partial, st)) return rc;
+    if (int rc = run_wgrad(delta_d, W / 2, W / 2, emb + in_x, in_all, in_d, P, grads + po.w_d + W, W + in_d, nullptr, partial, st)) return rc;
+    if (int rc = run_wgrad(d_raw, 4, 3, stash_g, W / 2, W / 2, P, grads + po.w_color, W / 2, grads + po.b_color, partial, st)) return rc;
+    return MI_NERF_OK;
+}
+
+int pack_apply(const int32_t* map_dev, const float* flat_dev, size_t blob_bytes, void* blob_dev, hipStream_t st) {
+    MN_CHECK_ARG(map_dev && flat_dev && blob_dev, "NULL device pointer");
+    MN_CHECK_ARG(blob_bytes % 4 == 0, "blob size must be a multiple of 4");
+    const long long n = (long long)(blob_bytes / 4);
+    if (n == 0) return MI_NERF_OK;
+    hipLaunchKernelGGL(pack_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, map_dev, flat_dev, n, (float*)blob_dev);
+    MN_LAUNCH_CHECK("pack_apply_kernel");
+    return MI_NERF_OK;
+}
+
+}  // namespace minerf

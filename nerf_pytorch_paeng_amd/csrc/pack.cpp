@@ -55,6 +55,26 @@ void emit_part(std::vector<float>& stream, const float* Wm, int n_out, int n_in,
     while (stream.size() % slot_floats) stream.push_back(0.0f);
 }
 
+
+// Transposed part for the backward-data chain: out = Wm[:, col_base : col_base + n_feat]^T x delta.
+// The k index runs over Wm's ROWS (the layer's outputs, held in accumulator layout: ks), the MFMA output
+// rows over its input columns.
+void emit_part_t(std::vector<float>& stream, const float* Wm, int n_rows, int ld, int col_base, int n_feat, int NT,
+                 const std::vector<KStep>& ks) {
+    const int KQ = (int)ks.size() / 4;
+    for (int kq = 0; kq < KQ; ++kq)
+        for (int T = 0; T < NT; ++T)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 4; ++j) {
+                    const KStep& k = ks[4 * kq + j];
+                    const int row = (lane >> 5) ? k.hi : k.lo;
+                    const int n = 32 * T + (lane & 31);
+                    stream.push_back((row >= 0 && row < n_rows && n < n_feat) ? Wm[(size_t)row * ld + col_base + n] : 0.0f);
+                }
+    const size_t slot_floats = SLOT_BYTES / 4;
+    while (stream.size() % slot_floats) stream.push_back(0.0f);
+}
+
 }  // namespace
 
 int pack_fp32(const mi_nerf_net* net, const mi_nerf_params* p, void* blob, size_t blob_bytes) {
@@ -95,6 +115,57 @@ int pack_fp32(const mi_nerf_net* net, const mi_nerf_params* p, void* blob, size_
     memcpy(side + L.color_b, p->linear_color_b, 3 * 4);
     for (int f = 0; f < in_d; ++f)
         for (int n = 0; n < W / 2; ++n) side[L.wdir_t + (size_t)f * (W / 2) + n] = p->linear_d_w[(size_t)n * (W + in_d) + W + f];
+    return MI_NERF_OK;
+}
+
+size_t packed_bytes_bwd(const mi_nerf_net* net) { return HEADER_BYTES + (size_t)bwd_stream_bytes(net->D, net->W); }
+
+int pack_bwd_fp32(const mi_nerf_net* net, const mi_nerf_params* p, void* blob, size_t blob_bytes) {
+    const int D = net->D, W = net->W, NT = W / 32;
+    const int in_x = 3 + 6 * net->L_x, in_d = 3 + 6 * net->L_d;
+    const size_t total = packed_bytes_bwd(net);
+    MN_CHECK_ARG(blob_bytes >= total, "blob too small: %zu < %zu", blob_bytes, total);
+    memset(blob, 0, total);
+    std::vector<float> stream;
+    stream.reserve((total - HEADER_BYTES) / 4);
+    emit_part_t(stream, p->linear_d_w, W / 2, W + in_d, 0, W, NT, act_ksteps(W / 2, 0));     // d feature = Wd[:, :W]^T d hidden
+    emit_part_t(stream, p->linear_feat_w, W, W, 0, W, NT, act_ksteps(W, 0));
+    for (int l = D - 1; l >= 1; --l) {
+        const bool cat = (net->skip >= 0 && l == net->skip + 1);
+        emit_part_t(stream, p->linear_x_w[l], W, cat ? W + in_x : W, cat ? in_x : 0, W, NT, act_ksteps(W, 0));
+    }
+    MN_CHECK_ARG(stream.size() * 4 + HEADER_BYTES == total, "internal: backward stream %zu != %zu", stream.size() * 4, total - HEADER_BYTES);
+    uint32_t* hdr = (uint32_t*)blob;
+    hdr[0] = BLOB_MAGIC; hdr[1] = 2; hdr[2] = D; hdr[3] = W; hdr[4] = (uint32_t)net->skip; hdr[5] = net->L_x; hdr[6] = net->L_d;
+    hdr[7] = HEADER_BYTES; hdr[8] = (uint32_t)(total - HEADER_BYTES);
+    memcpy((char*)blob + HEADER_BYTES, stream.data(), stream.size() * 4);
+    return MI_NERF_OK;
+}
+
+// Gather map for packing ON THE DEVICE (training re-packs after every optimiser step): run the host packer over a
+// parameter set whose values are their own flat indices + 1 (exact in fp32 below 2^24); every blob float then names
+// its source (0 = constant zero / header).  kind 0: forward blob, 1: backward-data blob.
+int pack_map(const mi_nerf_net* net, int kind, int32_t* map, size_t map_len) {
+    const int D = net->D, W = net->W;
+    const ParamOffsets po = make_param_offsets(D, W, net->skip, net->L_x, net->L_d);
+    MN_CHECK_ARG(po.total < (1u << 24), "network too large for the index map (%u parameters)", po.total);
+    MN_CHECK_ARG(kind == 0 || kind == 1, "kind must be 0 (forward) or 1 (backward)");
+    const size_t bytes = kind == 0 ? make_layout(D, W, net->skip, net->L_x, net->L_d).total_bytes : packed_bytes_bwd(net);
+    MN_CHECK_ARG(map && map_len * 4 >= bytes, "map too small: %zu entries for %zu bytes", map_len, bytes);
+    std::vector<float> flat(po.total);
+    for (uint32_t i = 0; i < po.total; ++i) flat[i] = (float)(i + 1);
+    std::vector<const float*> wx(D), bx(D);
+    for (int l = 0; l < D; ++l) { wx[l] = flat.data() + po.w_x[l]; bx[l] = flat.data() + po.b_x[l]; }
+    mi_nerf_params p{};
+    p.linear_x_w = wx.data(); p.linear_x_b = bx.data();
+    p.linear_density_w = flat.data() + po.w_dens; p.linear_density_b = flat.data() + po.b_dens;
+    p.linear_feat_w = flat.data() + po.w_feat; p.linear_feat_b = flat.data() + po.b_feat;
+    p.linear_d_w = flat.data() + po.w_d; p.linear_d_b = flat.data() + po.b_d;
+    p.linear_color_w = flat.data() + po.w_color; p.linear_color_b = flat.data() + po.b_color;
+    std::vector<float> blob(bytes / 4);
+    if (int rc = kind == 0 ? pack_fp32(net, &p, blob.data(), bytes) : pack_bwd_fp32(net, &p, blob.data(), bytes)) return rc;
+    for (size_t i = 0; i < HEADER_BYTES / 4; ++i) map[i] = 0;                   // header words are not floats
+    for (size_t i = HEADER_BYTES / 4; i < bytes / 4; ++i) map[i] = (int32_t)blob[i];
     return MI_NERF_OK;
 }
 

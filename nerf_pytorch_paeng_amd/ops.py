@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import _lib as L
-from ._lib import MiNerfError, Net, RenderCfg, WorkspaceLayout, check, dev_ptr, lib, stream_ptr
+from ._lib import MiNerfError, Net, RenderCfg, TrainLayout, WorkspaceLayout, check, dev_ptr, lib, stream_ptr
 
 
 def _guard(device):
@@ -29,9 +29,10 @@ def make_net(D: int, W: int, skip: int = 4, L_x: int = 10, L_d: int = 4) -> Net:
 # ------------------------------------------------------------------------------------------------
 # weights
 # ------------------------------------------------------------------------------------------------
-def pack_module(sd: Dict[str, "np.ndarray | torch.Tensor"], prefix: str, net: Net, bf16: bool = False) -> torch.Tensor:
+def pack_module(sd: Dict[str, "np.ndarray | torch.Tensor"], prefix: str, net: Net, bf16: bool = False, backward: bool = False) -> torch.Tensor:
     """Pack one NeRFModule (keys ``{prefix}linear_x.{i}.weight`` ...; model/NeRF.py:24-30) into the
-    kernels' streaming layout.  Returns a CPU uint8 tensor; copy it to the device once."""
+    kernels' streaming layout (``backward``: the transposed stream of the backward-data kernel).
+    Returns a CPU uint8 tensor; copy it to the device once."""
     def arr(key):
         v = sd[prefix + key]
         if isinstance(v, torch.Tensor):
@@ -57,8 +58,12 @@ def pack_module(sd: Dict[str, "np.ndarray | torch.Tensor"], prefix: str, net: Ne
                  ptr(arr("linear_feat.weight"), (W, W)), ptr(arr("linear_feat.bias"), (W,)),
                  ptr(arr("linear_d.weight"), (W // 2, W + in_d)), ptr(arr("linear_d.bias"), (W // 2,)),
                  ptr(arr("linear_color.weight"), (3, W // 2)), ptr(arr("linear_color.bias"), (3,)))
-    size_fn, pack_fn = ((lib().mi_nerf_packed_bytes_bf16, lib().mi_nerf_pack_weights_bf16) if bf16
-                        else (lib().mi_nerf_packed_bytes, lib().mi_nerf_pack_weights))
+    if backward:
+        size_fn, pack_fn = lib().mi_nerf_packed_bytes_bwd, lib().mi_nerf_pack_weights_bwd
+    elif bf16:
+        size_fn, pack_fn = lib().mi_nerf_packed_bytes_bf16, lib().mi_nerf_pack_weights_bf16
+    else:
+        size_fn, pack_fn = lib().mi_nerf_packed_bytes, lib().mi_nerf_pack_weights
     nbytes = size_fn(C.byref(net))
     if nbytes == 0:
         check(1, "mi_nerf_packed_bytes")
@@ -245,6 +250,121 @@ def composite_backward(raw: torch.Tensor, z: torch.Tensor, rays_or_d: torch.Tens
                                                dev_ptr(d_rgb, "d_rgb"), dev_ptr(d_raw, "d_raw", align=16), stream_ptr(z.device)),
               "mi_nerf_composite_backward")
     return d_raw
+
+
+# ------------------------------------------------------------------------------------------------
+# training path: stash forward, backward, device-side re-pack
+# ------------------------------------------------------------------------------------------------
+PARAM_ORDER = ("linear_x", "linear_d", "linear_feat", "linear_density", "linear_color")   # module.parameters() order, NeRF.py:24-30
+
+
+def param_count(net: Net) -> int:
+    n = lib().mi_nerf_param_count(C.byref(net))
+    if n == 0:
+        check(1, "mi_nerf_param_count")
+    return int(n)
+
+
+def param_names(net: Net):
+    """state_dict keys of one NeRFModule in flat-vector order."""
+    names = []
+    for l in range(net.D):
+        names += [f"linear_x.{l}.weight", f"linear_x.{l}.bias"]
+    for head in PARAM_ORDER[1:]:
+        names += [f"{head}.weight", f"{head}.bias"]
+    return names
+
+
+def flatten_params(sd, prefix: str, net: Net, device=None) -> torch.Tensor:
+    """cat of the module's parameters in flat-vector order (fp32)."""
+    flat = torch.cat([torch.as_tensor(sd[prefix + k]).detach().reshape(-1).float() for k in param_names(net)])
+    if flat.numel() != param_count(net):
+        raise MiNerfError(f"flat parameter vector has {flat.numel()} entries, expected {param_count(net)}")
+    return flat.to(device) if device is not None else flat
+
+
+def train_layout(net: Net, n_pts: int) -> TrainLayout:
+    lay = TrainLayout()
+    check(lib().mi_nerf_train_layout_query(C.byref(net), int(n_pts), C.byref(lay)), "mi_nerf_train_layout_query")
+    return lay
+
+
+def pack_map(net: Net, backward: bool = False) -> torch.Tensor:
+    """Gather map (CPU int32) from the flat parameter vector to the forward / backward-data blob."""
+    nbytes = (lib().mi_nerf_packed_bytes_bwd if backward else lib().mi_nerf_packed_bytes)(C.byref(net))
+    if nbytes == 0:
+        check(1, "mi_nerf_packed_bytes")
+    m = torch.empty(nbytes // 4, dtype=torch.int32)
+    check(lib().mi_nerf_pack_map(C.byref(net), int(backward), m.data_ptr(), m.numel()), "mi_nerf_pack_map")
+    return m
+
+
+def pack_apply(map_dev: torch.Tensor, flat: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Device-side pack: blob (uint8, 4*len(map) bytes) from the flat parameter vector."""
+    dev = flat.device
+    nbytes = map_dev.numel() * 4
+    if out is None:
+        out = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    if out.numel() != nbytes:
+        raise MiNerfError(f"blob must have {nbytes} bytes, got {out.numel()}")
+    with _guard(dev):
+        check(lib().mi_nerf_pack_apply(dev_ptr(map_dev, "map", torch.int32), dev_ptr(flat, "flat"), nbytes, dev_ptr(out, "blob", torch.uint8, 16),
+                                       stream_ptr(dev)), "mi_nerf_pack_apply")
+    return out
+
+
+def mlp_rays_train(net: Net, packed: torch.Tensor, rays: torch.Tensor, z: torch.Tensor, stash: Optional[torch.Tensor] = None):
+    """Training forward: raw [n,S,4] plus the activation stash the backward reads."""
+    n, S = z.shape
+    if tuple(rays.shape) != (n, 6):
+        raise MiNerfError(f"rays must be [n,6], got {tuple(rays.shape)}")
+    lay = train_layout(net, n * S)
+    if stash is None:
+        stash = torch.empty(lay.stash_bytes, dtype=torch.uint8, device=z.device)
+    raw = torch.empty(n, S, 4, dtype=torch.float32, device=z.device)
+    with _guard(z.device):
+        check(lib().mi_nerf_mlp_rays_train(C.byref(net), dev_ptr(packed, "packed", torch.uint8, 16), dev_ptr(rays, "rays"), dev_ptr(z, "z"), n, S,
+                                           dev_ptr(raw, "raw", align=16), dev_ptr(stash, "stash", torch.uint8, 16), stash.numel(),
+                                           stream_ptr(z.device)), "mi_nerf_mlp_rays_train")
+    return raw, stash
+
+
+def mlp_backward(net: Net, packed: torch.Tensor, packed_bwd: torch.Tensor, rays: torch.Tensor, z: torch.Tensor, d_raw: torch.Tensor,
+                 stash: torch.Tensor, work: Optional[torch.Tensor] = None, stage: int = 0):
+    """d_raw [n,S,4] -> flat parameter gradient (param_names order).  Returns (grads, work)."""
+    n, S = z.shape
+    if tuple(d_raw.shape) != (n, S, 4) or tuple(rays.shape) != (n, 6):
+        raise MiNerfError(f"d_raw must be {(n, S, 4)} and rays {(n, 6)}, got {tuple(d_raw.shape)} / {tuple(rays.shape)}")
+    lay = train_layout(net, n * S)
+    dev = z.device
+    if work is None:
+        work = torch.empty(lay.work_bytes, dtype=torch.uint8, device=dev)
+    grads = torch.zeros(param_count(net), dtype=torch.float32, device=dev)
+    with _guard(dev):
+        check(lib().mi_nerf_mlp_backward(C.byref(net), dev_ptr(packed, "packed", torch.uint8, 16), dev_ptr(packed_bwd, "packed_bwd", torch.uint8, 16),
+                                         dev_ptr(rays, "rays"), dev_ptr(z, "z"), n, S, dev_ptr(d_raw, "d_raw", align=16),
+                                         dev_ptr(stash, "stash", torch.uint8, 16), dev_ptr(work, "work", torch.uint8, 16), work.numel(),
+                                         dev_ptr(grads, "grads"), int(stage), stream_ptr(dev)), "mi_nerf_mlp_backward")
+    return grads, work
+
+
+def train_views(net: Net, n_pts: int, stash: Optional[torch.Tensor] = None, work: Optional[torch.Tensor] = None):
+    """Named float views into the stash / backward workspace (staged parity checks)."""
+    lay = train_layout(net, n_pts)
+    W, D = net.W, net.D
+    out = {}
+    def view(buf, off, shape):
+        cnt = int(np.prod(shape))
+        return buf[off:off + 4 * cnt].view(torch.float32).reshape(shape)
+    if stash is not None:
+        out["stash_h"] = view(stash, lay.stash_h, (D, n_pts, W))
+        out["stash_f"] = view(stash, lay.stash_f, (n_pts, W))
+        out["stash_g"] = view(stash, lay.stash_g, (n_pts, W // 2))
+    if work is not None:
+        out["delta_h"] = view(work, lay.delta_h, (D, n_pts, W))
+        out["delta_f"] = view(work, lay.delta_f, (n_pts, W))
+        out["delta_d"] = view(work, lay.delta_d, (n_pts, W // 2))
+    return out
 
 
 # ------------------------------------------------------------------------------------------------

@@ -201,9 +201,17 @@ def embed(rays: torch.Tensor, z_vals: torch.Tensor, L_x: int, L_d: int) -> torch
 # a9  the MLP                                                      model/NeRF.py:10-52
 # --------------------------------------------------------------------------------------------
 def mlp_forward(sd: Dict[str, torch.Tensor], prefix: str, x: torch.Tensor, D: int,
-                in_x: int, in_d: int, skips: Sequence[int] = (4,), dtype=F32) -> torch.Tensor:
+                in_x: int, in_d: int, skips: Sequence[int] = (4,), dtype=F32, taps: Optional[dict] = None) -> torch.Tensor:
     """One NeRFModule forward from a reference-layout ``state_dict`` (keys
-    ``{prefix}linear_x.{i}.weight`` ..., NeRF.py:24-30).  Returns [n, 4] = (rgb_raw, density_raw)."""
+    ``{prefix}linear_x.{i}.weight`` ..., NeRF.py:24-30).  Returns [n, 4] = (rgb_raw, density_raw).
+    ``taps`` (tests of the training path): collects the pre-activations ``a{i}``, ``feat``, ``ad`` (with
+    retain_grad when they carry a graph) so per-layer gradients can be compared."""
+    def tap(name, v):
+        if taps is not None:
+            if v.requires_grad:
+                v.retain_grad()
+            taps[name] = v
+        return v
     def lin(name, v):
         w = torch.as_tensor(sd[f"{prefix}{name}.weight"]).to(dtype)
         b = torch.as_tensor(sd[f"{prefix}{name}.bias"]).to(dtype)
@@ -212,12 +220,12 @@ def mlp_forward(sd: Dict[str, torch.Tensor], prefix: str, x: torch.Tensor, D: in
     gx, gd = x[:, :in_x], x[:, in_x:in_x + in_d]                  # NeRF.py:34
     h = gx
     for i in range(D):                                            # NeRF.py:37-41
-        h = torch.relu(lin(f"linear_x.{i}", h))
+        h = torch.relu(tap(f"a{i}", lin(f"linear_x.{i}", h)))
         if i in skips:
             h = torch.cat([gx, h], -1)                            # order: [input_x, out]
     sigma = lin("linear_density", h)                              # NeRF.py:43
-    feat = lin("linear_feat", h)                                  # NeRF.py:44 (no activation)
-    h = torch.relu(lin("linear_d", torch.cat([feat, gd], -1)))    # NeRF.py:46-48
+    feat = tap("feat", lin("linear_feat", h))                     # NeRF.py:44 (no activation)
+    h = torch.relu(tap("ad", lin("linear_d", torch.cat([feat, gd], -1))))    # NeRF.py:46-48
     rgb = lin("linear_color", h)                                  # NeRF.py:50
     return torch.cat([rgb, sigma], -1)                            # NeRF.py:51
 

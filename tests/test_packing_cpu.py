@@ -105,3 +105,74 @@ def test_model_mirror_has_reference_checkpoint_keys():
         assert m.get_camera_gt() == (None, None)
     with pytest.raises(_lib.MiNerfError):        # parameters on CPU: the MI355X path refuses, it never falls back
         m(torch.rand(2, 90))
+
+
+# ---------------------------------------------------------------------------------------------------
+# training path: backward-data blob, flat parameter order, device-pack maps
+# ---------------------------------------------------------------------------------------------------
+def _regs_from_rows(X):
+    """[32 points, F] -> [F/2, 64] per-lane B registers in accumulator layout"""
+    from tests.blob_emulator import COL, HH, _row_of
+    F = X.shape[1]
+    reg = np.zeros((F // 2, 64))
+    for s in range(F // 2):
+        reg[s] = X[COL, 32 * (s // 16) + _row_of(s % 16, HH)]
+    return reg
+
+
+def _rows_from_acc(acc, NT):
+    from tests.blob_emulator import COL, HH, _row_of
+    X = np.zeros((32, 32 * NT))
+    for t in range(NT):
+        for r in range(16):
+            X[COL, 32 * t + _row_of(r, HH)] = acc[t, r]
+    return X
+
+
+@pytest.mark.parametrize("D,W,skip", [(8, 256, 4), (4, 128, 1)])
+def test_backward_blob_emulation_is_the_transposed_chain(D, W, skip):
+    """Walk the backward-data stream with MFMA semantics (no ReLU masks: a pure layout check) and compare with
+    delta @ W[:, h-block] applied in the order mlp_dgrad_kernel consumes the parts."""
+    sd = synthetic.make_state_dict(21, D, W, skips=(skip,))
+    net = ops.make_net(D, W, skip)
+    prefix = "model_coarse."
+    blob = ops.pack_module(sd, prefix, net, backward=True).numpy()
+    hdr = np.frombuffer(blob[:64].tobytes(), dtype=np.uint32)
+    assert hdr[0] == 0x4D494E46 and hdr[1] == 2 and hdr[7] == 1024 and hdr[8] == blob.size - 1024
+    emu = Emu.__new__(Emu)
+    emu.stream = np.frombuffer(blob[1024:].tobytes(), dtype=np.float32).astype(np.float64)
+    emu.pos = 0
+    NT = W // 32
+    rs = np.random.RandomState(1)
+    delta = rs.normal(size=(32, W // 2))
+    w = lambda k: np.asarray(sd[prefix + k], dtype=np.float64)
+    chain = [w("linear_d.weight")[:, :W], w("linear_feat.weight")]
+    for l in range(D - 1, 0, -1):
+        wl = w(f"linear_x.{l}.weight")
+        chain.append(wl[:, 63:] if l == skip + 1 else wl)
+    for Wm in chain:
+        acc = emu.gemm_part(np.zeros((NT, 16, 64)), NT, _regs_from_rows(delta))
+        got = _rows_from_acc(acc, NT)
+        want = delta @ Wm
+        np.testing.assert_allclose(got, want, atol=1e-9 * np.abs(want).max(), rtol=1e-9)
+        delta = want
+    assert emu.pos * 1024 == blob.size - 1024
+
+
+def test_flat_parameter_order_and_pack_maps():
+    net = ops.make_net(8, 256, 4)
+    sd = synthetic.make_state_dict(4, 8, 256)
+    from nerf_pytorch_paeng_amd.model import NeRF
+    model = NeRF(8, 256, 63, 27)
+    names = [n for n, _ in model.model_coarse.named_parameters()]
+    assert names == ops.param_names(net)
+    assert sum(p.numel() for p in model.model_coarse.parameters()) == ops.param_count(net)
+    flat = ops.flatten_params(sd, "model_fine.", net)
+    for backward in (False, True):
+        mp = ops.pack_map(net, backward)
+        host = ops.pack_module(sd, "model_fine.", net, backward=backward).view(torch.float32)
+        out = torch.zeros(mp.numel())
+        nz = mp > 0
+        out[nz] = flat[(mp[nz] - 1).long()]
+        assert torch.equal(out[256:], host[256:])
+        assert int(mp.min()) == 0 and int(mp.max()) <= flat.numel()
