@@ -8,7 +8,10 @@ the reference draws unseeded ``torch.rand`` (nerf_process.py:58-60,162-163); her
 counter-based generator keyed on (seed, global ray index, sample index), so a frame renders
 identically however its rays are chunked or sharded across GPUs.
 
-Forward-only; inputs are borrowed, outputs are fresh fp32 tensors on the inputs' device.
+Under ``torch.no_grad()`` (test.py:36,140) this is the forward-only inference path.  With gradients enabled
+and a model whose parameters require them (train.py:53-70) the same entry points run the training path
+(train_path.py): same kernels plus an activation stash, hand-written backward behind one autograd node.
+Inputs are borrowed, outputs are fresh fp32 tensors on the inputs' device.
 ``opts`` fields read: near, far, N_samples_c, N_samples_f, perturb, chunk_rays, data_type
 (gpu_ids / rank / chunk_pts are accepted and unused: the device comes from the tensors and the fused
 kernel never materialises the [n_pts, 90] network input that chunk_pts exists to bound).
@@ -23,6 +26,7 @@ import torch
 from . import ops
 from ._lib import MiNerfError, as_f32_dev
 from .weights import PackedNeRF, packed_for
+from . import train_path
 
 # rays handed to one mi_nerf_render_rays call (workspace: 5.4 KB/ray at 64+128 samples -> ~5.6 GB)
 MAX_RAYS_PER_LAUNCH = 1 << 20
@@ -155,6 +159,12 @@ def render_rays(rays, model, posenc, opts, *, t_rand=None, u=None, seed=None, ra
                 return_intermediates: bool = False):
     """Coarse pass -> composite -> resample -> fine pass (nerf_process.py:185-216) as one fused launch
     sequence.  Returns ``{'rgb_c','disp_c'[,'rgb_f','disp_f']}``."""
+    if train_path.wants_grad(model):
+        if bf16 or return_intermediates:
+            raise MiNerfError("the training path is fp32 and returns no intermediates")
+        if rays.dim() != 2 or rays.shape[1] != 6:
+            raise MiNerfError(f"rays must be [n, 6] (o, d), got {tuple(rays.shape)}")
+        return train_path.render_train(rays, model, opts, t_rand=t_rand, u=u, seed=_next_seed(seed), ray_offset=int(ray_offset))
     packed = packed_for(model)
     rays = as_f32_dev(rays, packed.device)
     if rays.dim() != 2 or rays.shape[1] != 6:
@@ -170,8 +180,11 @@ def batchify_rays_and_render_by_chunk(ray_o, ray_d, model, posenc, H, W, K, opts
     ``opts.chunk_rays`` bounded the reference's activation memory; the fused kernels keep activations in
     registers, so rays are launched in slabs of up to MAX_RAYS_PER_LAUNCH.  The result does not depend on
     the slab size because the jitter is keyed on the global ray index (``ray_offset`` + position)."""
-    packed = packed_for(model)
-    dev = packed.device
+    training = train_path.wants_grad(model)
+    if training and bf16:
+        raise MiNerfError("the training path is fp32")
+    packed = None if training else packed_for(model)
+    dev = next(model.parameters()).device if training else packed.device
     ray_d = as_f32_dev(ray_d, dev)
     flat_d = ray_d.reshape(-1, 3)
     ray_o = ray_o.to(dev) if ray_o.device != dev else ray_o
@@ -185,10 +198,15 @@ def batchify_rays_and_render_by_chunk(ray_o, ray_d, model, posenc, H, W, K, opts
     seed = _next_seed(seed)
     Nf = int(opts.N_samples_f)
     parts = []
-    for i in range(0, N, MAX_RAYS_PER_LAUNCH):
-        j = min(N, i + MAX_RAYS_PER_LAUNCH)
-        parts.append(_render(rays[i:j], packed, opts, None if t_rand is None else t_rand[i:j], None if u is None else u[i:j],
-                             seed, int(ray_offset) + i, bf16, False))
+    slab = train_path.MAX_TRAIN_RAYS if training else MAX_RAYS_PER_LAUNCH
+    for i in range(0, N, slab):
+        j = min(N, i + slab)
+        tr, uu = (None if t_rand is None else t_rand[i:j]), (None if u is None else u[i:j])
+        if training:                                                # train.py:53-54: one autograd node per slab
+            parts.append(train_path.render_train(rays[i:j].contiguous(), model, opts, t_rand=tr, u=uu, seed=seed,
+                                                 ray_offset=int(ray_offset) + i))
+        else:
+            parts.append(_render(rays[i:j], packed, opts, tr, uu, seed, int(ray_offset) + i, bf16, False))
     def cat(key):
         return parts[0][key] if len(parts) == 1 else torch.cat([p[key] for p in parts], dim=0)
     if Nf > 0:

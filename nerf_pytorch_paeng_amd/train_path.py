@@ -1,0 +1,164 @@
+"""Training step of the hot path -- what the reference gets from autograd for train.py:53-70.
+
+``batchify_rays_and_render_by_chunk`` routes here when gradients are enabled and the model's parameters
+require them.  The forward runs the same kernels as inference (the MLP in its STASH variant, which also
+keeps every layer's activations), wrapped in ONE ``torch.autograd.Function`` whose inputs are the model's
+parameters; the backward is hand-written HIP (composite backward, backward-data chain, backward-weights)
+and returns one gradient per parameter, so ``loss.backward(); optimizer.step()`` work unchanged
+(train.py:69-70).  PyTorch does the bookkeeping (graph node, parameter ``.grad`` accumulation, the
+optimizer); no PyTorch kernel touches the activations.
+
+Semantics copied from the reference: only ``rgb_c`` / ``rgb_f`` carry gradient; the fine depths are
+detached (nerf_process.py:66), so the fine loss does not reach the coarse network; disparity outputs are
+not differentiable here (the reference's loss never reads them, train.py:60-66).
+"""
+from __future__ import annotations
+
+import weakref
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import ops
+from ._lib import MiNerfError, Net, as_f32_dev
+from .weights import infer_net
+
+# rays per autograd node: the activation stash is ~9.9 KB per sample point (W = 256, D = 8)
+MAX_TRAIN_RAYS = 16384
+
+
+class _TrainState:
+    """Per-model constants of the training path: network shape and the device-side pack maps."""
+
+    def __init__(self, model: torch.nn.Module, device: torch.device):
+        sd = model.state_dict()
+        self.net: Net = infer_net(sd)
+        self.device = device
+        self.names = ops.param_names(self.net)
+        self.map_fwd = ops.pack_map(self.net, False).to(device)
+        self.map_bwd = ops.pack_map(self.net, True).to(device)
+
+    def params(self, module: torch.nn.Module) -> List[torch.Tensor]:
+        named = dict(module.named_parameters())
+        try:
+            return [named[k] for k in self.names]
+        except KeyError as e:
+            raise MiNerfError(f"module lacks parameter {e} (expected the layout of model/NeRF.py:24-30)") from e
+
+
+_states: "weakref.WeakKeyDictionary[torch.nn.Module, _TrainState]" = weakref.WeakKeyDictionary()
+
+
+def _state_for(model: torch.nn.Module) -> _TrainState:
+    dev = next(model.parameters()).device
+    if dev.type != "cuda":
+        raise MiNerfError(f"model lives on {dev}: the MI355X path needs a HIP device (no CPU fallback)")
+    st = _states.get(model)
+    if st is None or st.device != dev:
+        st = _TrainState(model, dev)
+        _states[model] = st
+    return st
+
+
+def wants_grad(model) -> bool:
+    return (torch.is_grad_enabled() and isinstance(model, torch.nn.Module)
+            and any(p.requires_grad for p in model.parameters()))
+
+
+def _flat(params) -> torch.Tensor:
+    return torch.cat([p.detach().reshape(-1) for p in params]).float()
+
+
+class _RenderTrain(torch.autograd.Function):
+    """rays (+ explicit randomness) and the two networks' parameters -> rgb_c, disp_c, rgb_f, disp_f."""
+
+    @staticmethod
+    def forward(ctx, st: _TrainState, rays, cfg: Dict, t_rand, u, z_override, *params):
+        n_each = len(st.names)
+        net = st.net
+        Sc, Nf, det = cfg["Sc"], cfg["Nf"], cfg["det"]
+        flat_c = _flat(params[:n_each])
+        blob_c = ops.pack_apply(st.map_fwd, flat_c)
+        z_c = ops.stratified_z(cfg["near"], cfg["far"], t_rand) if z_override is None else z_override[0]
+        raw_c, stash_c = ops.mlp_rays_train(net, blob_c, rays, z_c)
+        rgb_c, disp_c, _, w_c, _ = ops.composite(raw_c, z_c, rays, want_all=True)
+        ctx.st, ctx.Nf = st, Nf
+        saved = [rays, flat_c, blob_c, z_c, raw_c, stash_c]
+        if Nf > 0:
+            flat_f = _flat(params[n_each:])
+            blob_f = ops.pack_apply(st.map_fwd, flat_f)
+            z_f = ops.fine_z(z_c, w_c, Nf, det, None if det else u) if (z_override is None or z_override[1] is None) else z_override[1]
+            raw_f, stash_f = ops.mlp_rays_train(net, blob_f, rays, z_f)
+            rgb_f, disp_f, *_ = ops.composite(raw_f, z_f, rays, want_all=False)
+            saved += [flat_f, blob_f, z_f, raw_f, stash_f]
+        else:
+            rgb_f = torch.empty(0, 3, device=rays.device)
+            disp_f = torch.empty(0, device=rays.device)
+        ctx.save_for_backward(*saved)
+        ctx.mark_non_differentiable(disp_c, disp_f)
+        ctx.set_materialize_grads(False)
+        return rgb_c, disp_c, rgb_f, disp_f
+
+    @staticmethod
+    def backward(ctx, g_rgb_c, g_disp_c, g_rgb_f, g_disp_f):
+        st: _TrainState = ctx.st
+        net = st.net
+        saved = ctx.saved_tensors
+        rays = saved[0]
+
+        def one(flat, blob, z, raw, stash, g_rgb) -> List[Optional[torch.Tensor]]:
+            if g_rgb is None:
+                return [None] * len(st.names)
+            blob_b = ops.pack_apply(st.map_bwd, flat)
+            d_raw = ops.composite_backward(raw, z, rays, g_rgb.contiguous().float())
+            grads, _ = ops.mlp_backward(net, blob, blob_b, rays, z, d_raw, stash)
+            out, off = [], 0
+            for k in st.names:
+                shape = _param_shape(net, k)
+                cnt = 1
+                for s in shape:
+                    cnt *= s
+                out.append(grads[off:off + cnt].view(shape))
+                off += cnt
+            return out
+
+        gc = one(*saved[1:6], g_rgb_c)
+        gf = one(*saved[6:11], g_rgb_f) if ctx.Nf > 0 else [None] * len(st.names)
+        return (None, None, None, None, None, None, *gc, *gf)
+
+
+def _param_shape(net: Net, key: str) -> Tuple[int, ...]:
+    W, in_x, in_d = net.W, 3 + 6 * net.L_x, 3 + 6 * net.L_d
+    mod, kind = key.rsplit(".", 1)
+    if mod.startswith("linear_x."):
+        l = int(mod.split(".")[1])
+        fan_in = in_x if l == 0 else (W + in_x if (net.skip >= 0 and l == net.skip + 1) else W)
+        out = W
+    else:
+        out, fan_in = {"linear_d": (W // 2, W + in_d), "linear_feat": (W, W), "linear_density": (1, W), "linear_color": (3, W // 2)}[mod]
+    return (out, fan_in) if kind == "weight" else (out,)
+
+
+def render_train(rays: torch.Tensor, model: torch.nn.Module, opts, *, t_rand=None, u=None, seed: int = 0, ray_offset: int = 0,
+                 z_override=None, det: Optional[bool] = None) -> Dict[str, torch.Tensor]:
+    """Differentiable ``render_rays`` (nerf_process.py:185-216) for one slab of rays [n, 6]."""
+    st = _state_for(model)
+    dev = st.device
+    rays = as_f32_dev(rays, dev)
+    n = rays.shape[0]
+    Sc, Nf = int(opts.N_samples_c), int(opts.N_samples_f)
+    if det is None:
+        p = getattr(opts, "perturb", 1.0)
+        det = isinstance(p, (int, float)) and p == 0.0
+    t_rand = ops.fill_uniform(seed, 0, ray_offset, n, Sc, dev) if t_rand is None else as_f32_dev(t_rand, dev)
+    if Nf > 0 and not det:
+        u = ops.fill_uniform(seed, 1, ray_offset, n, Nf, dev) if u is None else as_f32_dev(u, dev)
+    else:
+        u = None
+    cfg = {"near": float(opts.near), "far": float(opts.far), "Sc": Sc, "Nf": Nf, "det": bool(det)}
+    params = st.params(model.model_coarse) + st.params(model.model_fine)
+    rgb_c, disp_c, rgb_f, disp_f = _RenderTrain.apply(st, rays, cfg, t_rand, u, z_override, *params)
+    out = {"rgb_c": rgb_c, "disp_c": disp_c}
+    if Nf > 0:
+        out["rgb_f"], out["disp_f"] = rgb_f, disp_f
+    return out
