@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames", type=int, default=2, help="timed 800x800 frames (0 disables the frame metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--train-steps", type=int, default=8,
+                    help="timed training steps (forward + hand-written backward + Adam, train.py:53-70) reported as `train`; 0 disables")
     ap.add_argument("--bf16", action="store_true", help="bf16 MFMA variant (BASELINE config #5)")
     ap.add_argument("--workload", choices=["lego", "fern"], default="lego",
                     help="lego: BASELINE config #2 (default, the headline metric); fern: config #4, LLFF geometry + NDC rays")
@@ -177,6 +179,49 @@ def main():
         frame_ms = 1e3 * ft / args.frames
         assert rgb.shape == (H, W, 3) and torch.isfinite(rgb).all()
 
+    # ---- training step: forward + backward + Adam on this rank's 4096-ray batch --------------
+    train = None
+    if args.train_steps > 0 and not args.bf16:
+        from nerf_pytorch_paeng_amd.model import NeRF, get_positional_encoder
+        model = NeRF(8, 256, 63, 27).to(dev)
+        model.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+        posenc = get_positional_encoder(10), get_positional_encoder(4)
+        optim = torch.optim.Adam(model.parameters(), lr=5e-4, betas=(0.9, 0.999))          # main.py:79-80
+        target = torch.rand(N_RAYS, 3, generator=torch.Generator().manual_seed(rank)).to(dev)
+        NP.manual_seed(0)
+
+        def train_step():
+            rgb_c, _, rgb_f, _ = NP.batchify_rays_and_render_by_chunk(o, d, model, posenc, H, W, K, opts, ray_offset=rank * N_RAYS)
+            optim.zero_grad()
+            loss = torch.nn.functional.mse_loss(rgb_c, target) + torch.nn.functional.mse_loss(rgb_f, target)   # train.py:60-66
+            loss.backward()
+            optim.step()
+            return loss
+
+        for _ in range(2):
+            train_step()
+        torch.cuda.synchronize(dev)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.train_steps):
+            loss = train_step()
+        torch.cuda.synchronize(dev)
+        barrier()
+        tt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([tt], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            tt = float(tmax.item())
+        assert torch.isfinite(loss).all()
+        t_ms = 1e3 * tt / args.train_steps
+        train_flop_per_ray = 2 * (593408 + 557696 + 593408) * POINTS_PER_RAY            # forward + backward-data + backward-weights
+        train = {"ms_per_step": round(t_ms, 3), "rays_per_s": round(world * N_RAYS / (t_ms * 1e-3), 1), "steps": args.train_steps,
+                 "frac_of_f32_mfma_roofline": round(N_RAYS / (t_ms * 1e-3) * train_flop_per_ray / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                 "what": "batchify_rays_and_render_by_chunk (grad) + MSE(rgb_c)+MSE(rgb_f) + loss.backward() + Adam.step(), "
+                         f"{N_RAYS} rays per GPU, each rank an independent replica (the reference has no data-parallel training)"}
+        del model, optim
+        torch.cuda.empty_cache()
+
     # ---- CPU baseline: the oracle (a port: the reference cannot leave the build container) -------------------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -215,6 +260,8 @@ def main():
             "frac_of_f32_mfma_roofline_end_to_end": round(rays_per_s / world * FLOP_PER_RAY / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
             "roofline": roofline,
         }
+        if train is not None:
+            line["train"] = train
         if cpu is not None:
             line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)

@@ -87,8 +87,23 @@ __device__ __forceinline__ void ring_next_fetch(WRing& r) {
 // Start consuming the next slot.  The four DMAs of a slot are NOT issued here in a burst (every extra issue slot
 // between two MFMAs beyond ~8 delays the matrix pipe, tools/mfma_probe.hip): ring_read() issues DMA k together
 // with the read of the slot's quad k+1, i.e. spread over the four groups that follow the barrier.
-__device__ __forceinline__ void ring_advance(WRing& r) {
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+//
+// RELAX > 0 (training kernels): this wave issued RELAX global stores (activation / gradient rows) at the layer boundary
+// that precedes the current GEMM part.  Stores share vmcnt with the DMAs and retire in order, so the plain vmcnt(4)
+// would make the first advance of every layer wait out the full HBM write latency of those rows.  Queue at the first
+// two advances after the boundary (old -> new): [DMA p+1] [DMA p+2] [DMA p+3, at least 3 of 4] [stores] [rest] ...:
+// the slot being entered has landed once everything except the newest 8 + RELAX operations has retired.  (The third
+// advance is strict again: with 4-quad prefetches the last DMA of slot p+3 is issued AFTER the stores.)  Only valid
+// when the stores really were issued (wave-uniform `relaxed`), otherwise the count would under-wait.
+template <int RELAX = 0>
+__device__ __forceinline__ void ring_advance(WRing& r, bool relaxed = false) {
+    if constexpr (RELAX > 0) {
+        static_assert(8 + RELAX <= 63, "vmcnt is a 6-bit counter");
+        if (relaxed) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + RELAX) : "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    }
     __syncthreads();
     ring_next_fetch(r);
     r.read_slot = (r.read_slot + 1) & (NSLOT - 1);
@@ -112,9 +127,9 @@ __device__ __forceinline__ f32x4 ring_read(const char* smem, const WRing& r, int
 // MFMA order is t-major: 4 back-to-back dependent MFMAs per tile (dependent issue = 64 cycles = the
 // issue interval of v_mfma_f32_32x32x2_f32, so the chain costs nothing).
 // ---------------------------------------------------------------------------------------------
-template <int NT, int KS, int NT_NEXT, int NB>
+template <int NT, int KS, int NT_NEXT, int NSTORE = 0, int NB = 0>
 __device__ __forceinline__ void gemm_part(f32x16 (&acc)[8], const float (&b)[NB], f32x4 (&a)[8], const char* smem,
-                                          WRing& ring, int lane) {
+                                          WRing& ring, int lane, bool stores_issued = false) {
     static_assert(KS % 4 == 0 && KS <= NB, "k-steps come in quads");
     constexpr int KQ = KS / 4;
 #pragma unroll
@@ -126,10 +141,16 @@ __device__ __forceinline__ void gemm_part(f32x16 (&acc)[8], const float (&b)[NB]
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][j], b[4 * kq + j], acc[t], 0, 0, 0);
             if (kq + 1 < KQ) {
                 const int q = (kq + 1) * NT + t;                       // quad index inside this part
-                if (q % SLOT_QUADS == 0) ring_advance(ring);
+                if (q % SLOT_QUADS == 0) {
+                    if (NSTORE > 0 && q / SLOT_QUADS <= 2) ring_advance<NSTORE>(ring, stores_issued);   // first two advances after the boundary
+                    else ring_advance(ring);
+                }
                 a[t] = ring_read(smem, ring, lane, q % SLOT_QUADS);
             } else if (t < NT_NEXT) {
-                if (t == 0) ring_advance(ring);                        // next part starts a fresh slot
+                if (t == 0) {                                          // next part starts a fresh slot
+                    if (NSTORE > 0 && (KQ * NT) / SLOT_QUADS <= 2) ring_advance<NSTORE>(ring, stores_issued);
+                    else ring_advance(ring);
+                }
                 a[t] = ring_read(smem, ring, lane, t);
             }
             // pin the (4 MFMA, 1 LDS read) group order: left alone, hipcc sinks each read to just before

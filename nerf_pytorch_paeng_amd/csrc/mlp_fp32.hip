@@ -88,6 +88,7 @@ void mlp_fp32_kernel(const MlpArgs a) {
     constexpr int KPE = pe_ksteps(LX);  // 32
     constexpr int KDE = pe_ksteps(LD);  // 16
     constexpr int IN_X = 3 + 6 * LX, IN_D = 3 + 6 * LD;
+    constexpr int NST = STASH ? 4 * NT : 0;   // row stores per lane at a layer boundary (store_rows)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* side = (float*)(smem + RING_BYTES);
     const int tid = threadIdx.x;
@@ -223,8 +224,10 @@ void mlp_fp32_kernel(const MlpArgs a) {
             acc_to_b<NT, true>(acc, h);
             if constexpr (STASH) store_rows<NT>(h, a.stash_h + ((long long)(l - 1) * a.stash_rows + out_idx) * W + 4 * hh, valid);
             acc_init<NT>(acc, side + a.o_bias_trunk + l * W, hh);
-            if (l == a.skip_layer) gemm_part<NT, KPE, NT>(acc, pe, aq, smem, ring, lane);   // cat([gamma(x), h]) order
-            gemm_part<NT, HN, NT>(acc, h, aq, smem, ring, lane);
+            // STASH: the 4*NT row stores above share vmcnt with the weight DMAs (ring_advance<RELAX>)
+            const bool cat = (l == a.skip_layer);
+            if (cat) gemm_part<NT, KPE, NT, NST>(acc, pe, aq, smem, ring, lane, wave_active);   // cat([gamma(x), h]) order
+            gemm_part<NT, HN, NT, NST>(acc, h, aq, smem, ring, lane, wave_active && !cat);      // strict again behind the pe part
         }
         acc_to_b<NT, true>(acc, h);
         if constexpr (STASH) store_rows<NT>(h, a.stash_h + ((long long)(a.D - 1) * a.stash_rows + out_idx) * W + 4 * hh, valid);
@@ -233,14 +236,14 @@ void mlp_fp32_kernel(const MlpArgs a) {
         const float dens = xhalf_sum(dot_half<HN>(h, side + a.o_dens_w, hh)) + side[a.o_dens_b];
         // ---- feature layer (no activation) ----
         acc_init<NT>(acc, side + a.o_bias_feat, hh);
-        gemm_part<NT, HN, NT / 2>(acc, h, aq, smem, ring, lane);
+        gemm_part<NT, HN, NT / 2, NST>(acc, h, aq, smem, ring, lane, wave_active);
         acc_to_b<NT, false>(acc, h);
         if constexpr (STASH) store_rows<NT>(h, a.stash_f + out_idx * W + 4 * hh, valid);
         MN_STAMP(3);   // density head + feature layer
         // ---- view-direction layer ----
         if constexpr (MODE == 0) {
             acc_init<NT / 2>(acc, scratch, hh);
-            gemm_part<NT / 2, HN, NT>(acc, h, aq, smem, ring, lane);
+            gemm_part<NT / 2, HN, NT, NST>(acc, h, aq, smem, ring, lane, wave_active);
         } else {
             acc_init<NT / 2>(acc, side + a.o_bias_d, hh);
             gemm_part<NT / 2, HN, NT / 2>(acc, h, aq, smem, ring, lane);

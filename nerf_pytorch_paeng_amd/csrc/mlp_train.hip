@@ -124,12 +124,12 @@ void mlp_dgrad_kernel(const DgradArgs a) {
         store_rows<NT / 2>(h2, a.delta_d + idx * (W / 2) + 4 * hh, valid);
         // ---- linear_d^T, feature block: d feature = Wd[:, :W]^T delta_d ----
         acc_zero<NT>(acc);
-        gemm_part<NT, HN / 2, NT>(acc, h2, aq, smem, ring, lane);
+        gemm_part<NT, HN / 2, NT, 2 * NT>(acc, h2, aq, smem, ring, lane, wave_active);
         acc_to_b<NT, false>(acc, h);
         store_rows<NT>(h, a.delta_f + idx * W + 4 * hh, valid);
         // ---- linear_feat^T (+ density head^T, rank 1) -> gradient of the trunk output ----
         acc_zero<NT>(acc);
-        gemm_part<NT, HN, NT>(acc, h, aq, smem, ring, lane);
+        gemm_part<NT, HN, NT, 4 * NT>(acc, h, aq, smem, ring, lane, wave_active);
         // ---- trunk, last layer first ----
 #pragma unroll 1
         for (int l = a.D - 1;; --l) {
@@ -148,7 +148,7 @@ void mlp_dgrad_kernel(const DgradArgs a) {
             store_rows<NT>(h, a.delta_h + ((long long)l * a.P + idx) * W + 4 * hh, valid);
             if (l == 0) break;
             acc_zero<NT>(acc);
-            gemm_part<NT, HN, NT>(acc, h, aq, smem, ring, lane);                  // W_l[:, h-block]^T delta_l
+            gemm_part<NT, HN, NT, 4 * NT>(acc, h, aq, smem, ring, lane, wave_active);   // W_l[:, h-block]^T delta_l
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -168,88 +168,129 @@ struct WgradArgs {
     int Mp, Np;
 };
 
-// Workgroup = 2x2 waves, each wave TM x TN tiles of 32x32: block (64 TM) x (64 TN) of dW.
-template <int TM, int TN>
+// masked lanes / rows past the slice end load zeros from here WITHOUT a branch (a value select after the load makes
+// hipcc wrap every load in its own exec-masked block with an immediate s_waitcnt: 6x slower).  Never written.
+__device__ float g_zero16[4];
+
+// 256 x 256 block of dW per workgroup: 2x2 waves, each 4x4 MFMA tiles (all 256 accumulator registers).
+// Operand fetch: ONE 16-byte load per lane per point pair and operand: lane i takes columns 4i..4i+3, i.e. MFMA tile
+// t of this wave covers columns {4i + t}.  Any bijection lane <-> column works as long as the store uses the same one.
+// Requires M, N, ldd, ldx multiples of 4 and 16-byte aligned operands (true for every W-wide layer).
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
-void wgrad_kernel(const WgradArgs a) {
+void wgrad_big_kernel(const WgradArgs a) {
     constexpr int U = 6;                  // k-steps (2 points each) per software-pipeline stage
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 31, kh = lane >> 5;
-    const int m0 = blockIdx.y * (64 * TM) + (wave >> 1) * (32 * TM);
-    const int n0 = blockIdx.z * (64 * TN) + (wave & 1) * (32 * TN);
+    const int m0 = blockIdx.y * 256 + (wave >> 1) * 128;
+    const int n0 = blockIdx.z * 256 + (wave & 1) * 128;
     const long long pb = (long long)blockIdx.x * a.pps;
     const long long pe = (pb + a.pps < a.P) ? pb + a.pps : a.P;
+    const bool aok = m0 + 4 * i < a.M, bok = n0 + 4 * i < a.N;
+    const float* abase = a.dlt + m0 + 4 * i;
+    const float* bbase = a.x + n0 + 4 * i;
+    const f32x4* zp = (const f32x4*)g_zero16;
 
-    const float* ap[TM]; bool aok[TM];
-    const float* bp[TN]; bool bok[TN];
+    f32x16 acc[4][4];
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm) { const int c = m0 + 32 * tm + i; aok[tm] = c < a.M; ap[tm] = a.dlt + (aok[tm] ? c : a.M - 1); }
+    for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn) { const int c = n0 + 32 * tn + i; bok[tn] = c < a.N; bp[tn] = a.x + (bok[tn] ? c : a.N - 1); }
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
+        for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.0f;
-    float bsum[TM];
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm) bsum[tm] = 0.0f;
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
 
-    float ca[U][TM], cb[U][TN], na[U][TM], nb[U][TN];
-    auto load = [&](long long p, float (&A)[U][TM], float (&B)[U][TN]) __attribute__((always_inline)) {
+    f32x4 ca[U], cb[U], na[U], nb[U];
+    auto load = [&](long long p, f32x4 (&A)[U], f32x4 (&B)[U]) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const long long row = p + 2 * u + kh;
             const bool ok = row < pe;
-            const long long r = ok ? row : pe - 1;
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm) { const float v = ap[tm][r * a.ldd]; A[u][tm] = (ok && aok[tm]) ? v : 0.0f; }
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn) { const float v = bp[tn][r * a.ldx]; B[u][tn] = (ok && bok[tn]) ? v : 0.0f; }
+            const f32x4* qa = (ok && aok) ? (const f32x4*)(abase + row * a.ldd) : zp;
+            const f32x4* qb = (ok && bok) ? (const f32x4*)(bbase + row * a.ldx) : zp;
+            A[u] = *qa;
+            B[u] = *qb;
         }
     };
     load(pb, ca, cb);
     for (long long p = pb; p < pe; p += 2 * U) {
-        load(p + 2 * U, na, nb);          // past the slice end: clamped address, zero value
+        load(p + 2 * U, na, nb);          // past the slice end: zeros
 #pragma unroll
         for (int u = 0; u < U; ++u) {
+            bsum += ca[u];
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm) {
-                bsum[tm] += ca[u][tm];
+            for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
-                for (int tn = 0; tn < TN; ++tn)
+                for (int tn = 0; tn < 4; ++tn)
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[u][tm], cb[u][tn], acc[tm][tn], 0, 0, 0);
-            }
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm) ca[u][tm] = na[u][tm];
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn) cb[u][tn] = nb[u][tn];
-        }
+        for (int u = 0; u < U; ++u) { ca[u] = na[u]; cb[u] = nb[u]; }
     }
-    // D[i'][j]: row i' = (r&3) + 8*(r>>2) + 4*kh (delta feature), column j = lane & 31 (input feature)
+    // D[i'][j]: i' = (r&3) + 8*(r>>2) + 4*kh is the A-side lane index, j = lane & 31 the B-side one
     float* out = a.partial + (size_t)blockIdx.x * a.Mp * a.Np;
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
+    for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + 32 * tm + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                out[(size_t)m * a.Np + n0 + 32 * tn + i] = acc[tm][tn][r];
-            }
-    if (a.bpartial && blockIdx.z == 0 && (wave & 1) == 0) {
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-            const float s = bsum[tm] + __shfl_xor(bsum[tm], 32, 64);     // even + odd points of every k-step
-            if (kh == 0) a.bpartial[(size_t)blockIdx.x * a.Mp + m0 + 32 * tm + i] = s;
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + 4 * ((r & 3) + 8 * (r >> 2) + 4 * kh) + tm;
+            f32x4 v; v[0] = acc[tm][0][r]; v[1] = acc[tm][1][r]; v[2] = acc[tm][2][r]; v[3] = acc[tm][3][r];
+            *(f32x4*)(out + (size_t)m * a.Np + n0 + 4 * i) = v;
         }
+    if (a.bpartial && blockIdx.z == 0 && (wave & 1) == 0) {
+        f32x4 s;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[e] = bsum[e] + __shfl_xor(bsum[e], 32, 64);      // even + odd points of every k-step
+        if (kh == 0) *(f32x4*)(a.bpartial + (size_t)blockIdx.x * a.Mp + m0 + 4 * i) = s;
+    }
+}
+
+// 64 x 64 block per workgroup (2x2 waves, one tile each) for the narrow operands: encoded inputs (63 / 27 columns,
+// row pitch 90), the 3-wide colour and 1-wide density gradients.  HBM bound; many small workgroups per CU.
+__global__ __launch_bounds__(256)
+void wgrad_small_kernel(const WgradArgs a) {
+    constexpr int U = 8;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = lane & 31, kh = lane >> 5;
+    const int m0 = blockIdx.y * 64 + (wave >> 1) * 32;
+    const int n0 = blockIdx.z * 64 + (wave & 1) * 32;
+    const long long pb = (long long)blockIdx.x * a.pps;
+    const long long pe = (pb + a.pps < a.P) ? pb + a.pps : a.P;
+    const bool aok = m0 + i < a.M, bok = n0 + i < a.N;
+    const float* abase = a.dlt + m0 + i;
+    const float* bbase = a.x + n0 + i;
+    const float* zp = g_zero16;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    float bsum = 0.0f;
+    for (long long p = pb; p < pe; p += 2 * U) {
+        float ca[U], cb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long row = p + 2 * u + kh;
+            const bool ok = row < pe;
+            const float* qa = (ok && aok) ? abase + row * a.ldd : zp;
+            const float* qb = (ok && bok) ? bbase + row * a.ldx : zp;
+            ca[u] = *qa;
+            cb[u] = *qb;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            bsum += ca[u];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[u], cb[u], acc, 0, 0, 0);
+        }
+    }
+    float* out = a.partial + (size_t)blockIdx.x * a.Mp * a.Np;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        out[(size_t)m * a.Np + n0 + i] = acc[r];
+    }
+    if (a.bpartial && blockIdx.z == 0 && (wave & 1) == 0) {
+        const float s = bsum + __shfl_xor(bsum, 32, 64);
+        if (kh == 0) a.bpartial[(size_t)blockIdx.x * a.Mp + m0 + i] = s;
     }
 }
 
@@ -332,22 +373,27 @@ static int run_wgrad(const float* dlt, int ldd, int M, const float* x, int ldx, 
     WgradArgs a{};
     a.dlt = dlt; a.ldd = ldd; a.M = M; a.x = x; a.ldx = ldx; a.N = N; a.P = P;
     const bool big = (M > 64 && N > 64);
+    if (big)
+        MN_CHECK_ARG(M % 4 == 0 && N % 4 == 0 && ldd % 4 == 0 && ldx % 4 == 0 && ((uintptr_t)dlt & 15) == 0 && ((uintptr_t)x & 15) == 0,
+                     "internal: wgrad operands must be 16-byte aligned with pitches of 4 floats");
     const int bm = big ? 256 : 64, bn = big ? 256 : 64;
     const int by = (M + bm - 1) / bm, bz = (N + bn - 1) / bn;
     a.Mp = by * bm; a.Np = bz * bn;
-    int slices = num_cus_t() / (by * bz);
+    // big: one workgroup per CU owns all registers; small: ~8 workgroups per CU hide the HBM latency by occupancy
+    int slices = (big ? num_cus_t() : 8 * num_cus_t()) / (by * bz);
+    const size_t per_slice = (size_t)a.Mp * a.Np + a.Mp;
+    if ((size_t)slices * per_slice > WGRAD_PARTIAL_FLOATS) slices = (int)(WGRAD_PARTIAL_FLOATS / per_slice);
     if (slices < 1) slices = 1;
-    if (slices > 256) slices = 256;
     long long pps = (P + slices - 1) / slices;
     pps = (pps + 15) / 16 * 16;
     slices = (int)((P + pps - 1) / pps);
-    MN_CHECK_ARG((size_t)slices * a.Mp * a.Np + (size_t)slices * a.Mp <= WGRAD_PARTIAL_FLOATS, "internal: wgrad partial buffer too small");
+    MN_CHECK_ARG((size_t)slices * per_slice <= WGRAD_PARTIAL_FLOATS, "internal: wgrad partial buffer too small");
     a.pps = (int)pps;
     a.partial = partial;
     a.bpartial = bias ? partial + (size_t)slices * a.Mp * a.Np : nullptr;
     const dim3 grid(slices, by, bz);
-    if (big) hipLaunchKernelGGL((wgrad_kernel<4, 4>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((wgrad_kernel<1, 1>), grid, dim3(256), 0, st, a);
+    if (big) hipLaunchKernelGGL(wgrad_big_kernel, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(wgrad_small_kernel, grid, dim3(256), 0, st, a);
     MN_LAUNCH_CHECK("wgrad_kernel");
     const int total = M * N + (bias ? M : 0);
     hipLaunchKernelGGL(reduce_partial_kernel, dim3((total + 255) / 256), dim3(256), 0, st, (const float*)partial, (const float*)a.bpartial,

@@ -25,3 +25,7 @@ for _ in range(3):
     ops.mlp_rays(packed.net, packed.fine, rays, z)
 torch.cuda.synchronize()
 print("ideal MFMA cycles per tile: layer0 16384, trunk 475136, feature 65536, viewdir 32768, total 589824")
+if len(sys.argv) > 2 and sys.argv[2] == "stash":
+    print("---- training forward (STASH) ----")
+    ops.mlp_rays_train(packed.net, packed.fine, rays, z)
+    torch.cuda.synchronize()
