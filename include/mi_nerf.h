@@ -185,13 +185,14 @@ int mi_nerf_pack_apply(const int32_t* map_dev, const float* flat_params_dev, siz
 
 /* Activation stash written by the training forward and the scratch the backward needs (byte offsets). */
 typedef struct mi_nerf_train_layout {
-    size_t stash_h, stash_f, stash_g, stash_bytes;               /* [D][P][W], [P][W], [P][W/2] post-activation rows */
+    size_t stash_h, stash_f, stash_g;                            /* [D][P][W], [P][W], [P][W/2] post-activation rows, P = n_rays*S */
+    size_t mask_h, mask_g, stash_bytes;                          /* ReLU' bit masks in the kernels' (ray, 32-sample tile, lane) order */
     size_t delta_h, delta_f, delta_d, emb, partial, work_bytes;  /* pre-activation gradients, encoded inputs, wgrad partials */
 } mi_nerf_train_layout;
-int mi_nerf_train_layout_query(const mi_nerf_net* net, int64_t n_pts, mi_nerf_train_layout* out);
+int mi_nerf_train_layout_query(const mi_nerf_net* net, int64_t n_rays, int S, mi_nerf_train_layout* out);
 
 /* Training forward: mi_nerf_mlp_rays that also keeps every layer's activations (model/NeRF.py:33-52 with the
- * autograd graph the reference builds implicitly).  stash: mi_nerf_train_layout.stash_bytes for n_rays*S points. */
+ * autograd graph the reference builds implicitly).  stash: mi_nerf_train_layout.stash_bytes for (n_rays, S). */
 int mi_nerf_mlp_rays_train(const mi_nerf_net* net, const void* packed_dev, const float* rays_dev, const float* z_dev,
                            int64_t n_rays, int S, float* raw_dev, void* stash_dev, size_t stash_bytes, void* stream);
 /* Backward of the above: d_raw [n_rays*S, 4] -> grads [mi_nerf_param_count] (overwritten, not accumulated).

@@ -43,8 +43,8 @@ class WorkspaceLayout(C.Structure):   # mi_nerf_workspace_layout
 
 
 class TrainLayout(C.Structure):       # mi_nerf_train_layout
-    _fields_ = [(n, C.c_size_t) for n in ("stash_h", "stash_f", "stash_g", "stash_bytes", "delta_h", "delta_f", "delta_d", "emb",
-                                          "partial", "work_bytes")]
+    _fields_ = [(n, C.c_size_t) for n in ("stash_h", "stash_f", "stash_g", "mask_h", "mask_g", "stash_bytes", "delta_h", "delta_f",
+                                          "delta_d", "emb", "partial", "work_bytes")]
 
 
 _P, _I, _I64, _F, _U32, _SZ = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32, C.c_size_t
@@ -81,7 +81,7 @@ SIGNATURES = {
     "mi_nerf_pack_weights_bwd": (_I, [_NETP, C.POINTER(Params), _P, _SZ]),
     "mi_nerf_pack_map": (_I, [_NETP, _I, _P, _SZ]),
     "mi_nerf_pack_apply": (_I, [_P, _P, _SZ, _P, _P]),
-    "mi_nerf_train_layout_query": (_I, [_NETP, _I64, C.POINTER(TrainLayout)]),
+    "mi_nerf_train_layout_query": (_I, [_NETP, _I64, _I, C.POINTER(TrainLayout)]),
     "mi_nerf_mlp_rays_train": (_I, [_NETP, _P, _P, _P, _I64, _I, _P, _P, _SZ, _P]),
     "mi_nerf_mlp_backward": (_I, [_NETP, _P, _P, _P, _P, _I64, _I, _P, _P, _P, _SZ, _P, _I, _P]),
     "mi_nerf_time_mlp_rays": (_I, [_NETP, _P, _P, _P, _I64, _I, _P, _I, _I, C.POINTER(_F), _P]),

@@ -26,10 +26,11 @@ size_t packed_bytes_bf16(const mi_nerf_net*);
 int mlp_rays_fp32(const mi_nerf_net*, const void*, const float*, const float*, int64_t, int, float*, hipStream_t);
 int mlp_embedded_fp32(const mi_nerf_net*, const void*, const float*, int64_t, float*, hipStream_t);
 int mlp_rays_bf16(const mi_nerf_net*, const void*, const float*, const float*, int64_t, int, float*, hipStream_t);
-int mlp_rays_fp32_stash(const mi_nerf_net*, const void*, const float*, const float*, int64_t, int, float*, float*, float*, float*, hipStream_t);
+int mlp_rays_fp32_stash(const mi_nerf_net*, const void*, const float*, const float*, int64_t, int, float*, float*, float*, float*, unsigned*,
+                        unsigned*, hipStream_t);
 int mlp_backward_fp32(const mi_nerf_net*, const void*, const void*, const float*, const float*, int64_t, int, const float*, const void*, void*,
                       size_t, float*, int, hipStream_t);
-int train_layout(const mi_nerf_net*, int64_t, mi_nerf_train_layout*);
+int train_layout(const mi_nerf_net*, int64_t, int, mi_nerf_train_layout*);
 int pack_apply(const int32_t*, const float*, size_t, void*, hipStream_t);
 int pack_bwd_fp32(const mi_nerf_net*, const mi_nerf_params*, void*, size_t);
 size_t packed_bytes_bwd(const mi_nerf_net*);
@@ -197,20 +198,21 @@ int mi_nerf_pack_map(const mi_nerf_net* net, int kind, int32_t* map_host, size_t
 int mi_nerf_pack_apply(const int32_t* map_dev, const float* flat_dev, size_t blob_bytes, void* blob_dev, void* st) {
     return pack_apply(map_dev, flat_dev, blob_bytes, blob_dev, (hipStream_t)st);
 }
-int mi_nerf_train_layout_query(const mi_nerf_net* net, int64_t n_pts, mi_nerf_train_layout* out) {
+int mi_nerf_train_layout_query(const mi_nerf_net* net, int64_t n_rays, int S, mi_nerf_train_layout* out) {
     if (int rc = check_net_basic(net)) return rc;
-    return train_layout(net, n_pts, out);
+    return train_layout(net, n_rays, S, out);
 }
 int mi_nerf_mlp_rays_train(const mi_nerf_net* net, const void* packed, const float* rays, const float* z, int64_t n_rays, int S,
                            float* raw, void* stash, size_t stash_bytes, void* st) {
     if (int rc = check_net_basic(net)) return rc;
     MN_CHECK_ARG(n_rays >= 0 && S >= 1, "bad sizes n_rays=%lld S=%d", (long long)n_rays, S);
     mi_nerf_train_layout L;
-    if (int rc = train_layout(net, n_rays * S, &L)) return rc;
+    if (int rc = train_layout(net, n_rays, S, &L)) return rc;
     if (n_rays == 0) return MI_NERF_OK;
     MN_CHECK_ARG(stash != nullptr && stash_bytes >= L.stash_bytes, "stash too small: %zu < %zu", stash_bytes, L.stash_bytes);
     return mlp_rays_fp32_stash(net, packed, rays, z, n_rays, S, raw, (float*)((char*)stash + L.stash_h), (float*)((char*)stash + L.stash_f),
-                               (float*)((char*)stash + L.stash_g), (hipStream_t)st);
+                               (float*)((char*)stash + L.stash_g), (unsigned*)((char*)stash + L.mask_h), (unsigned*)((char*)stash + L.mask_g),
+                               (hipStream_t)st);
 }
 int mi_nerf_mlp_backward(const mi_nerf_net* net, const void* packed, const void* packed_bwd, const float* rays, const float* z,
                          int64_t n_rays, int S, const float* d_raw, const void* stash, void* work, size_t work_bytes, float* grads,

@@ -88,22 +88,14 @@ __device__ __forceinline__ void ring_next_fetch(WRing& r) {
 // between two MFMAs beyond ~8 delays the matrix pipe, tools/mfma_probe.hip): ring_read() issues DMA k together
 // with the read of the slot's quad k+1, i.e. spread over the four groups that follow the barrier.
 //
-// RELAX > 0 (training kernels): this wave issued RELAX global stores (activation / gradient rows) at the layer boundary
-// that precedes the current GEMM part.  Stores share vmcnt with the DMAs and retire in order, so the plain vmcnt(4)
-// would make the first advance of every layer wait out the full HBM write latency of those rows.  Queue at the first
-// two advances after the boundary (old -> new): [DMA p+1] [DMA p+2] [DMA p+3, at least 3 of 4] [stores] [rest] ...:
-// the slot being entered has landed once everything except the newest 8 + RELAX operations has retired.  (The third
-// advance is strict again: with 4-quad prefetches the last DMA of slot p+3 is issued AFTER the stores.)  Only valid
-// when the stores really were issued (wave-uniform `relaxed`), otherwise the count would under-wait.
-template <int RELAX = 0>
-__device__ __forceinline__ void ring_advance(WRing& r, bool relaxed = false) {
-    if constexpr (RELAX > 0) {
-        static_assert(8 + RELAX <= 63, "vmcnt is a 6-bit counter");
-        if (relaxed) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + RELAX) : "memory");
-        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    }
+// ALLOW = operations that may still be in flight.  The slot being entered (p) is followed in the queue by the DMAs of
+// slots p+1 and p+2 (4 each), so any ALLOW <= 8 is correct; 4 keeps one slot of slack (inference kernels).  The
+// training kernels interleave one row store per k-quad with the DMAs (stores share vmcnt and retire in order): with
+// ALLOW = 8 a store has one to two slot phases (4-8k cycles) to reach memory before an advance waits for it.
+template <int ALLOW = 4>
+__device__ __forceinline__ void ring_advance(WRing& r) {
+    static_assert(ALLOW >= 0 && ALLOW <= 8, "more than 8 outstanding operations could include the entered slot's DMAs");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ALLOW) : "memory");
     __syncthreads();
     ring_next_fetch(r);
     r.read_slot = (r.read_slot + 1) & (NSLOT - 1);
@@ -127,9 +119,15 @@ __device__ __forceinline__ f32x4 ring_read(const char* smem, const WRing& r, int
 // MFMA order is t-major: 4 back-to-back dependent MFMAs per tile (dependent issue = 64 cycles = the
 // issue interval of v_mfma_f32_32x32x2_f32, so the chain costs nothing).
 // ---------------------------------------------------------------------------------------------
-template <int NT, int KS, int NT_NEXT, int NSTORE = 0, int NB = 0>
+struct NoHook { __device__ __forceinline__ void operator()(int, int) const {} };
+
+// `hook(kq, t)` runs inside the pinned group (kq, t) after its MFMAs and LDS read, with compile-time-constant
+// arguments once the loops are unrolled: the training kernels use it to spread their row stores (and the ReLU-mask
+// packing) over the GEMM that consumes the same registers, instead of a burst at the layer boundary that would block
+// the texture-address path (shared by the 4 waves and by the weight DMAs) for ~9k cycles per layer.
+template <int NT, int KS, int NT_NEXT, int ALLOW = 4, typename Hook = NoHook, int NB = 0>
 __device__ __forceinline__ void gemm_part(f32x16 (&acc)[8], const float (&b)[NB], f32x4 (&a)[8], const char* smem,
-                                          WRing& ring, int lane, bool stores_issued = false) {
+                                          WRing& ring, int lane, Hook hook = Hook()) {
     static_assert(KS % 4 == 0 && KS <= NB, "k-steps come in quads");
     constexpr int KQ = KS / 4;
 #pragma unroll
@@ -141,18 +139,13 @@ __device__ __forceinline__ void gemm_part(f32x16 (&acc)[8], const float (&b)[NB]
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][j], b[4 * kq + j], acc[t], 0, 0, 0);
             if (kq + 1 < KQ) {
                 const int q = (kq + 1) * NT + t;                       // quad index inside this part
-                if (q % SLOT_QUADS == 0) {
-                    if (NSTORE > 0 && q / SLOT_QUADS <= 2) ring_advance<NSTORE>(ring, stores_issued);   // first two advances after the boundary
-                    else ring_advance(ring);
-                }
+                if (q % SLOT_QUADS == 0) ring_advance<ALLOW>(ring);
                 a[t] = ring_read(smem, ring, lane, q % SLOT_QUADS);
             } else if (t < NT_NEXT) {
-                if (t == 0) {                                          // next part starts a fresh slot
-                    if (NSTORE > 0 && (KQ * NT) / SLOT_QUADS <= 2) ring_advance<NSTORE>(ring, stores_issued);
-                    else ring_advance(ring);
-                }
+                if (t == 0) ring_advance<ALLOW>(ring);                 // next part starts a fresh slot
                 a[t] = ring_read(smem, ring, lane, t);
             }
+            hook(kq, t);
             // pin the (4 MFMA, 1 LDS read) group order: left alone, hipcc sinks each read to just before
             // its first use and exposes the LDS latency on every tile
             __builtin_amdgcn_sched_barrier(0);
@@ -220,6 +213,36 @@ __device__ __forceinline__ void store_rows(const float (&h)[NB], float* row, boo
             *(f32x4*)(row + 8 * q) = v;
         }
     }
+}
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+// chunk q (registers 4q..4q+3 = features 8q + 4hh + {0..3}) of a B-operand register set -> its row (one 16-byte store)
+template <int NB>
+__device__ __forceinline__ void store_chunk(const float (&h)[NB], int q, float* row, bool valid) {
+    if (valid) {
+        f32x4 v; v[0] = h[4 * q + 0]; v[1] = h[4 * q + 1]; v[2] = h[4 * q + 2]; v[3] = h[4 * q + 3];
+        *(f32x4*)(row + 8 * q) = v;
+    }
+}
+
+// ReLU' bit masks: bit 4*(q&7)+e of word q>>3 <=> register 4q+e is > 0.  The registers are post-ReLU (+0.0 or positive,
+// relu_pinned), so "non-zero bit pattern" == "> 0": min(bits, 1) shifted into place, 2 VALU per value.
+template <int NB, int NW>
+__device__ __forceinline__ void mask_pack_chunk(const float (&h)[NB], int q, unsigned (&mw)[NW]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const unsigned ubits = __float_as_uint(h[4 * q + e]);
+        const unsigned bit = ubits < 1u ? ubits : 1u;
+        mw[q >> 3] |= bit << (4 * (q & 7) + e);
+    }
+}
+// register 4q+e masked by its bit: sign-extend the 1-bit field to 0 / ~0 and AND the float's bits (2 VALU)
+template <int NW>
+__device__ __forceinline__ float mask_apply(float v, int q, int e, const unsigned (&mw)[NW]) {
+    const int m = ((int)(mw[q >> 3] << (31 - (4 * (q & 7) + e)))) >> 31;
+    return __uint_as_float(__float_as_uint(v) & (unsigned)m);
 }
 
 __device__ __forceinline__ float xhalf_sum(float v) { return v + __shfl_xor(v, 32, 64); }

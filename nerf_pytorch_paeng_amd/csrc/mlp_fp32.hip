@@ -45,6 +45,8 @@ struct MlpArgs {
     float* stash_h;           // [D][P][W]   post-ReLU output of trunk layer l
     float* stash_f;           // [P][W]      linear_feat output
     float* stash_g;           // [P][W/2]    post-ReLU linear_d output
+    unsigned* mask_h;         // [D][n_wtiles][64 lanes][4]  ReLU' bits of stash_h in the kernel's register order
+    unsigned* mask_g;         // [n_wtiles][64 lanes][2]     ... of stash_g
     long long stash_rows;
 };
 
@@ -88,7 +90,7 @@ void mlp_fp32_kernel(const MlpArgs a) {
     constexpr int KPE = pe_ksteps(LX);  // 32
     constexpr int KDE = pe_ksteps(LD);  // 16
     constexpr int IN_X = 3 + 6 * LX, IN_D = 3 + 6 * LD;
-    constexpr int NST = STASH ? 4 * NT : 0;   // row stores per lane at a layer boundary (store_rows)
+    constexpr int AL = STASH ? 8 : 4;         // ring_advance<ALLOW>: the training forward interleaves row stores with the DMAs
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* side = (float*)(smem + RING_BYTES);
     const int tid = threadIdx.x;
@@ -216,34 +218,67 @@ void mlp_fp32_kernel(const MlpArgs a) {
 
         MN_STAMP(0);   // prologue
         // ---- trunk ----
+        // STASH (training forward): every activation row is written while the NEXT GEMM consumes the same registers as
+        // its B operand -- one 16-byte store per k-quad from the group hook -- and the ReLU' bit masks are packed there too.
         acc_init<NT>(acc, side + a.o_bias_trunk, hh);
-        gemm_part<NT, KPE, NT>(acc, pe, aq, smem, ring, lane);
+        gemm_part<NT, KPE, NT, AL>(acc, pe, aq, smem, ring, lane);
         MN_STAMP(1);   // layer 0
 #pragma unroll 1
         for (int l = 1; l < a.D; ++l) {
             acc_to_b<NT, true>(acc, h);
-            if constexpr (STASH) store_rows<NT>(h, a.stash_h + ((long long)(l - 1) * a.stash_rows + out_idx) * W + 4 * hh, valid);
             acc_init<NT>(acc, side + a.o_bias_trunk + l * W, hh);
-            // STASH: the 4*NT row stores above share vmcnt with the weight DMAs (ring_advance<RELAX>)
-            const bool cat = (l == a.skip_layer);
-            if (cat) gemm_part<NT, KPE, NT, NST>(acc, pe, aq, smem, ring, lane, wave_active);   // cat([gamma(x), h]) order
-            gemm_part<NT, HN, NT, NST>(acc, h, aq, smem, ring, lane, wave_active && !cat);      // strict again behind the pe part
+            if (l == a.skip_layer) gemm_part<NT, KPE, NT, AL>(acc, pe, aq, smem, ring, lane);   // cat([gamma(x), h]) order
+            if constexpr (STASH) {
+                float* row = a.stash_h + ((long long)(l - 1) * a.stash_rows + out_idx) * W + 4 * hh;
+                unsigned mw[4] = {0u, 0u, 0u, 0u};
+                auto hook = [&](int kq, int t) __attribute__((always_inline)) {
+                    if (t == NT - 1) store_chunk(h, kq, row, valid);
+                    else if (t == NT - 2) mask_pack_chunk(h, kq, mw);
+                };
+                gemm_part<NT, HN, NT, AL>(acc, h, aq, smem, ring, lane, hook);
+                if (wave_active) {
+                    u32x4 m; m[0] = mw[0]; m[1] = mw[1]; m[2] = mw[2]; m[3] = mw[3];
+                    *(u32x4*)(a.mask_h + (((long long)(l - 1) * a.n_wtiles + wt) * 64 + lane) * 4) = m;
+                }
+            } else {
+                gemm_part<NT, HN, NT>(acc, h, aq, smem, ring, lane);
+            }
         }
         acc_to_b<NT, true>(acc, h);
-        if constexpr (STASH) store_rows<NT>(h, a.stash_h + ((long long)(a.D - 1) * a.stash_rows + out_idx) * W + 4 * hh, valid);
         MN_STAMP(2);   // trunk layers 1..D-1
         // ---- density head (VALU dot over the trunk output) ----
         const float dens = xhalf_sum(dot_half<HN>(h, side + a.o_dens_w, hh)) + side[a.o_dens_b];
         // ---- feature layer (no activation) ----
         acc_init<NT>(acc, side + a.o_bias_feat, hh);
-        gemm_part<NT, HN, NT / 2, NST>(acc, h, aq, smem, ring, lane, wave_active);
+        if constexpr (STASH) {
+            float* row = a.stash_h + ((long long)(a.D - 1) * a.stash_rows + out_idx) * W + 4 * hh;
+            unsigned mw[4] = {0u, 0u, 0u, 0u};
+            auto hook = [&](int kq, int t) __attribute__((always_inline)) {
+                if (t == NT - 1) store_chunk(h, kq, row, valid);
+                else if (t == NT - 2) mask_pack_chunk(h, kq, mw);
+            };
+            gemm_part<NT, HN, NT / 2, AL>(acc, h, aq, smem, ring, lane, hook);
+            if (wave_active) {
+                u32x4 m; m[0] = mw[0]; m[1] = mw[1]; m[2] = mw[2]; m[3] = mw[3];
+                *(u32x4*)(a.mask_h + (((long long)(a.D - 1) * a.n_wtiles + wt) * 64 + lane) * 4) = m;
+            }
+        } else {
+            gemm_part<NT, HN, NT / 2>(acc, h, aq, smem, ring, lane);
+        }
         acc_to_b<NT, false>(acc, h);
-        if constexpr (STASH) store_rows<NT>(h, a.stash_f + out_idx * W + 4 * hh, valid);
         MN_STAMP(3);   // density head + feature layer
         // ---- view-direction layer ----
         if constexpr (MODE == 0) {
             acc_init<NT / 2>(acc, scratch, hh);
-            gemm_part<NT / 2, HN, NT, NST>(acc, h, aq, smem, ring, lane, wave_active);
+            if constexpr (STASH) {
+                float* row = a.stash_f + out_idx * W + 4 * hh;
+                auto hook = [&](int kq, int t) __attribute__((always_inline)) {
+                    if (t == NT / 2 - 1) store_chunk(h, kq, row, valid);
+                };
+                gemm_part<NT / 2, HN, NT, AL>(acc, h, aq, smem, ring, lane, hook);
+            } else {
+                gemm_part<NT / 2, HN, NT>(acc, h, aq, smem, ring, lane);
+            }
         } else {
             acc_init<NT / 2>(acc, side + a.o_bias_d, hh);
             gemm_part<NT / 2, HN, NT / 2>(acc, h, aq, smem, ring, lane);
@@ -251,7 +286,16 @@ void mlp_fp32_kernel(const MlpArgs a) {
         }
         float h2[HN / 2];
         acc_to_b<NT / 2, true>(acc, h2);
-        if constexpr (STASH) store_rows<NT / 2>(h2, a.stash_g + out_idx * (W / 2) + 4 * hh, valid);
+        if constexpr (STASH) {      // nothing consumes h2 as a B operand: 4*NT/2 row stores and its mask in one go
+            store_rows<NT / 2>(h2, a.stash_g + out_idx * (W / 2) + 4 * hh, valid);
+            unsigned mg[2] = {0u, 0u};
+#pragma unroll
+            for (int q = 0; q < HN / 8; ++q) mask_pack_chunk(h2, q, mg);
+            if (wave_active) {
+                u32x2 m; m[0] = mg[0]; m[1] = mg[1];
+                *(u32x2*)(a.mask_g + (wt * 64 + lane) * 2) = m;
+            }
+        }
         MN_STAMP(4);   // view-direction layer
         // ---- colour head ----
         const float* cw = side + a.o_color_w;
@@ -378,16 +422,18 @@ int mlp_rays_fp32(const mi_nerf_net* net, const void* packed_dev, const float* r
 
 // training forward: same kernel, additionally keeping every layer's activations row-major for the backward pass
 int mlp_rays_fp32_stash(const mi_nerf_net* net, const void* packed_dev, const float* rays_dev, const float* z_dev,
-                        int64_t n_rays, int S, float* raw_dev, float* stash_h, float* stash_f, float* stash_g, hipStream_t st) {
+                        int64_t n_rays, int S, float* raw_dev, float* stash_h, float* stash_f, float* stash_g, unsigned* mask_h,
+                        unsigned* mask_g, hipStream_t st) {
     if (int rc = check_net(net)) return rc;
     MN_CHECK_ARG(n_rays >= 0 && S >= 1, "bad sizes n_rays=%lld S=%d", (long long)n_rays, S);
     if (n_rays == 0) return MI_NERF_OK;
-    MN_CHECK_ARG(packed_dev && rays_dev && z_dev && raw_dev && stash_h && stash_f && stash_g, "NULL device pointer");
+    MN_CHECK_ARG(packed_dev && rays_dev && z_dev && raw_dev && stash_h && stash_f && stash_g && mask_h && mask_g, "NULL device pointer");
     MlpArgs a{};
     fill_common(a, net, packed_dev, false);
     a.rays = rays_dev; a.z = z_dev; a.out = raw_dev; a.S = S; a.tpr = (S + 31) / 32;
     a.n_wtiles = (long long)n_rays * a.tpr;
     a.stash_h = stash_h; a.stash_f = stash_f; a.stash_g = stash_g; a.stash_rows = (long long)n_rays * S;
+    a.mask_h = mask_h; a.mask_g = mask_g;
     return net->W == 256 ? launch<256, 0, true>(a, a.n_wtiles, st) : launch<128, 0, true>(a, a.n_wtiles, st);
 }
 

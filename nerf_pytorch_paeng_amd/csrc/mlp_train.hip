@@ -30,13 +30,14 @@ struct DgradArgs {
     const float* side;        // forward blob's side tables (colour / density head weights)
     unsigned side_floats, o_dens_w, o_color_w;
     const float* d_raw;       // [P][4]  dL/d(rgb_raw, density_raw)
-    const float* stash_h;     // [D][P][W]
-    const float* stash_g;     // [P][W/2]
+    const unsigned* mask_h;   // [D][n_wtiles][64][4]  ReLU' bits written by the training forward (same tiling, same lanes)
+    const unsigned* mask_g;   // [n_wtiles][64][2]
     float* delta_h;           // [D][P][W]   dL/d(pre-activation of trunk layer l)
     float* delta_f;           // [P][W]      dL/d(linear_feat output)
     float* delta_d;           // [P][W/2]    dL/d(pre-activation of linear_d)
     long long P;
-    long long n_wtiles;
+    long long n_wtiles;       // n_rays * tpr: the forward's (ray, 32-sample chunk) tiles
+    int S, tpr;
     int D;
 };
 
@@ -53,6 +54,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void mlp_dgrad_kernel(const DgradArgs a) {
     constexpr int NT = W / 32;
     constexpr int HN = W / 2;
+    constexpr int AL = 8;               // ring_advance<ALLOW>: row stores are interleaved with the weight DMAs
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* side = (float*)(smem + RING_BYTES);
     const int tid = threadIdx.x;
@@ -96,59 +98,70 @@ void mlp_dgrad_kernel(const DgradArgs a) {
         long long wt = wgt * 4 + wave;
         const bool wave_active = wt < a.n_wtiles;
         if (!wave_active) wt = a.n_wtiles - 1;
-        const long long p0 = wt * 32 + col;
-        const bool valid = wave_active && p0 < a.P;
-        const long long idx = p0 < a.P ? p0 : a.P - 1;
+        const long long ray = wt / a.tpr;
+        const int sample = (int)(wt - ray * a.tpr) * 32 + col;
+        const bool valid = wave_active && sample < a.S;
+        const long long idx = ray * a.S + (sample < a.S ? sample : a.S - 1);
         f32x4 dr = *(const f32x4*)(a.d_raw + idx * 4);
         if (!valid) { dr[0] = 0.f; dr[1] = 0.f; dr[2] = 0.f; dr[3] = 0.f; }
+        const u32x2 mgv = *(const u32x2*)(a.mask_g + (wt * 64 + lane) * 2);
+        u32x4 mhv = *(const u32x4*)(a.mask_h + (((long long)(a.D - 1) * a.n_wtiles + wt) * 64 + lane) * 4);
 
         // ---- colour head^T (VALU, 3 inputs) and ReLU' of linear_d ----
         float h2[HN / 2];
         {
-            const float* grow = a.stash_g + idx * (W / 2) + 4 * hh;
+            const unsigned mg[2] = {mgv[0], mgv[1]};
 #pragma unroll
             for (int q = 0; q < HN / 8; ++q) {
                 const f32x4 w0 = *(const f32x4*)(cw + 8 * q + 4 * hh);
                 const f32x4 w1 = *(const f32x4*)(cw + W / 2 + 8 * q + 4 * hh);
                 const f32x4 w2 = *(const f32x4*)(cw + W + 8 * q + 4 * hh);
-                const f32x4 g = *(const f32x4*)(grow + 8 * q);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float v = dr[0] * w0[j];
-                    v = __builtin_fmaf(dr[1], w1[j], v);
-                    v = __builtin_fmaf(dr[2], w2[j], v);
-                    h2[4 * q + j] = g[j] > 0.0f ? v : 0.0f;
+                for (int e = 0; e < 4; ++e) {
+                    float v = dr[0] * w0[e];
+                    v = __builtin_fmaf(dr[1], w1[e], v);
+                    v = __builtin_fmaf(dr[2], w2[e], v);
+                    h2[4 * q + e] = mask_apply(v, q, e, mg);
                 }
             }
         }
-        store_rows<NT / 2>(h2, a.delta_d + idx * (W / 2) + 4 * hh, valid);
+        // every delta row is written by the GEMM that consumes it as its B operand: one 16-byte store per k-quad
         // ---- linear_d^T, feature block: d feature = Wd[:, :W]^T delta_d ----
         acc_zero<NT>(acc);
-        gemm_part<NT, HN / 2, NT, 2 * NT>(acc, h2, aq, smem, ring, lane, wave_active);
+        {
+            float* row = a.delta_d + idx * (W / 2) + 4 * hh;
+            auto hook = [&](int kq, int t) __attribute__((always_inline)) { if (t == NT - 1) store_chunk(h2, kq, row, valid); };
+            gemm_part<NT, HN / 2, NT, AL>(acc, h2, aq, smem, ring, lane, hook);
+        }
         acc_to_b<NT, false>(acc, h);
-        store_rows<NT>(h, a.delta_f + idx * W + 4 * hh, valid);
         // ---- linear_feat^T (+ density head^T, rank 1) -> gradient of the trunk output ----
         acc_zero<NT>(acc);
-        gemm_part<NT, HN, NT, 4 * NT>(acc, h, aq, smem, ring, lane, wave_active);
+        {
+            float* row = a.delta_f + idx * W + 4 * hh;
+            auto hook = [&](int kq, int t) __attribute__((always_inline)) { if (t == NT - 1) store_chunk(h, kq, row, valid); };
+            gemm_part<NT, HN, NT, AL>(acc, h, aq, smem, ring, lane, hook);
+        }
         // ---- trunk, last layer first ----
 #pragma unroll 1
         for (int l = a.D - 1;; --l) {
-            const float* hrow = a.stash_h + ((long long)l * a.P + idx) * W + 4 * hh;
             const float ds = (l == a.D - 1) ? dr[3] : 0.0f;
+            const unsigned mw[4] = {mhv[0], mhv[1], mhv[2], mhv[3]};
+            if (l > 0) mhv = *(const u32x4*)(a.mask_h + (((long long)(l - 1) * a.n_wtiles + wt) * 64 + lane) * 4);   // a layer ahead
 #pragma unroll
             for (int q = 0; q < 4 * NT; ++q) {
-                const f32x4 hv = *(const f32x4*)(hrow + 8 * q);
                 const f32x4 wv = *(const f32x4*)(dw + 8 * q + 4 * hh);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float v = __builtin_fmaf(wv[j], ds, acc[q >> 2][4 * (q & 3) + j]);
-                    h[4 * q + j] = hv[j] > 0.0f ? v : 0.0f;                       // ReLU'
-                }
+                for (int e = 0; e < 4; ++e)
+                    h[4 * q + e] = mask_apply(__builtin_fmaf(wv[e], ds, acc[q >> 2][4 * (q & 3) + e]), q, e, mw);    // ReLU'
             }
-            store_rows<NT>(h, a.delta_h + ((long long)l * a.P + idx) * W + 4 * hh, valid);
-            if (l == 0) break;
+            float* row = a.delta_h + ((long long)l * a.P + idx) * W + 4 * hh;
+            if (l == 0) {
+                store_rows<NT>(h, row, valid);      // no GEMM consumes delta_0 (there is no gradient w.r.t. gamma(x))
+                break;
+            }
             acc_zero<NT>(acc);
-            gemm_part<NT, HN, NT, 4 * NT>(acc, h, aq, smem, ring, lane, wave_active);   // W_l[:, h-block]^T delta_l
+            auto hook = [&](int kq, int t) __attribute__((always_inline)) { if (t == NT - 1) store_chunk(h, kq, row, valid); };
+            gemm_part<NT, HN, NT, AL>(acc, h, aq, smem, ring, lane, hook);          // W_l[:, h-block]^T delta_l
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -345,17 +358,20 @@ static inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 constexpr size_t WGRAD_PARTIAL_FLOATS = (size_t)256 * 256 * 256 + (size_t)256 * 256;   // 256 slices of a 256x256 block + bias rows
 
-int train_layout(const mi_nerf_net* net, int64_t P, mi_nerf_train_layout* L) {
+int train_layout(const mi_nerf_net* net, int64_t n_rays, int S, mi_nerf_train_layout* L) {
     MN_CHECK_ARG(net && L, "NULL net/layout");
     MN_CHECK_ARG(net->W == 256 || net->W == 128, "unsupported width W=%d", net->W);
     MN_CHECK_ARG(net->D >= 2 && net->D <= 16, "unsupported depth D=%d", net->D);
-    MN_CHECK_ARG(P >= 0, "bad point count %lld", (long long)P);
-    const size_t p = (size_t)P, W = (size_t)net->W, D = (size_t)net->D;
+    MN_CHECK_ARG(n_rays >= 0 && S >= 1, "bad sizes n_rays=%lld S=%d", (long long)n_rays, S);
+    const size_t p = (size_t)n_rays * S, W = (size_t)net->W, D = (size_t)net->D;
+    const size_t n_wtiles = (size_t)n_rays * ((S + 31) / 32);
     const size_t in_all = (size_t)(3 + 6 * net->L_x) + (size_t)(3 + 6 * net->L_d);
     size_t off = 0;
     L->stash_h = off; off += al256(D * p * W * 4);
     L->stash_f = off; off += al256(p * W * 4);
     L->stash_g = off; off += al256(p * (W / 2) * 4);
+    L->mask_h = off;  off += al256(D * n_wtiles * 64 * 16);
+    L->mask_g = off;  off += al256(n_wtiles * 64 * 8);
     L->stash_bytes = off;
     off = 0;
     L->delta_h = off; off += al256(D * p * W * 4);
@@ -431,7 +447,7 @@ int mlp_backward_fp32(const mi_nerf_net* net, const void* packed_fwd, const void
     MN_CHECK_ARG(n_rays >= 0 && S >= 1, "bad sizes n_rays=%lld S=%d", (long long)n_rays, S);
     const long long P = (long long)n_rays * S;
     mi_nerf_train_layout L;
-    if (int rc = train_layout(net, P, &L)) return rc;
+    if (int rc = train_layout(net, n_rays, S, &L)) return rc;
     if (P == 0) return MI_NERF_OK;
     MN_CHECK_ARG(packed_fwd && packed_bwd && rays && z && d_raw && stash && work && grads, "NULL device pointer");
     MN_CHECK_ARG(work_bytes >= L.work_bytes, "workspace too small: %zu < %zu", work_bytes, L.work_bytes);
@@ -453,9 +469,12 @@ int mlp_backward_fp32(const mi_nerf_net* net, const void* packed_fwd, const void
     a.stream_bytes = bwd_stream_bytes(D, W);
     a.side = (const float*)((const char*)packed_fwd + BL.side_off);
     a.side_floats = BL.side_floats; a.o_dens_w = BL.dens_w; a.o_color_w = BL.color_w;
-    a.d_raw = d_raw; a.stash_h = stash_h; a.stash_g = stash_g;
+    a.d_raw = d_raw;
+    a.mask_h = (const unsigned*)((const char*)stash + L.mask_h);
+    a.mask_g = (const unsigned*)((const char*)stash + L.mask_g);
     a.delta_h = delta_h; a.delta_f = delta_f; a.delta_d = delta_d;
-    a.P = P; a.n_wtiles = (P + 31) / 32; a.D = D;
+    a.S = S; a.tpr = (S + 31) / 32;
+    a.P = P; a.n_wtiles = (long long)n_rays * a.tpr; a.D = D;
     if (int rc = (W == 256 ? launch_dgrad<256>(a, st) : launch_dgrad<128>(a, st))) return rc;
     if (stage == 1) return MI_NERF_OK;
 

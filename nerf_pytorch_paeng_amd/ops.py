@@ -283,9 +283,9 @@ def flatten_params(sd, prefix: str, net: Net, device=None) -> torch.Tensor:
     return flat.to(device) if device is not None else flat
 
 
-def train_layout(net: Net, n_pts: int) -> TrainLayout:
+def train_layout(net: Net, n_rays: int, S: int) -> TrainLayout:
     lay = TrainLayout()
-    check(lib().mi_nerf_train_layout_query(C.byref(net), int(n_pts), C.byref(lay)), "mi_nerf_train_layout_query")
+    check(lib().mi_nerf_train_layout_query(C.byref(net), int(n_rays), int(S), C.byref(lay)), "mi_nerf_train_layout_query")
     return lay
 
 
@@ -318,7 +318,7 @@ def mlp_rays_train(net: Net, packed: torch.Tensor, rays: torch.Tensor, z: torch.
     n, S = z.shape
     if tuple(rays.shape) != (n, 6):
         raise MiNerfError(f"rays must be [n,6], got {tuple(rays.shape)}")
-    lay = train_layout(net, n * S)
+    lay = train_layout(net, n, S)
     if stash is None:
         stash = torch.empty(lay.stash_bytes, dtype=torch.uint8, device=z.device)
     raw = torch.empty(n, S, 4, dtype=torch.float32, device=z.device)
@@ -335,7 +335,7 @@ def mlp_backward(net: Net, packed: torch.Tensor, packed_bwd: torch.Tensor, rays:
     n, S = z.shape
     if tuple(d_raw.shape) != (n, S, 4) or tuple(rays.shape) != (n, 6):
         raise MiNerfError(f"d_raw must be {(n, S, 4)} and rays {(n, 6)}, got {tuple(d_raw.shape)} / {tuple(rays.shape)}")
-    lay = train_layout(net, n * S)
+    lay = train_layout(net, n, S)
     dev = z.device
     if work is None:
         work = torch.empty(lay.work_bytes, dtype=torch.uint8, device=dev)
@@ -348,9 +348,10 @@ def mlp_backward(net: Net, packed: torch.Tensor, packed_bwd: torch.Tensor, rays:
     return grads, work
 
 
-def train_views(net: Net, n_pts: int, stash: Optional[torch.Tensor] = None, work: Optional[torch.Tensor] = None):
+def train_views(net: Net, n_rays: int, S: int, stash: Optional[torch.Tensor] = None, work: Optional[torch.Tensor] = None):
     """Named float views into the stash / backward workspace (staged parity checks)."""
-    lay = train_layout(net, n_pts)
+    lay = train_layout(net, n_rays, S)
+    n_pts = n_rays * S
     W, D = net.W, net.D
     out = {}
     def view(buf, off, shape):

@@ -98,7 +98,7 @@ def test_mlp_backward_vs_autograd(D, W, skip, n, S):
     raw, stash = ops.mlp_rays_train(net, packed, raysd, zd)
     assert torch.equal(raw, ops.mlp_rays(net, packed, raysd, zd))
     assert rel_err(raw.reshape(-1, 4), raw_want) < 2e-5
-    v = ops.train_views(net, P, stash=stash)
+    v = ops.train_views(net, n, S, stash=stash)
     for l in range(D):
         assert rel_err(v["stash_h"][l], torch.relu(taps[f"a{l}"]).detach()) < 2e-5, f"stash_h[{l}]"
     assert rel_err(v["stash_f"], taps["feat"].detach()) < 2e-5
@@ -108,7 +108,7 @@ def test_mlp_backward_vs_autograd(D, W, skip, n, S):
     # flip between the two implementations; such rows are rare and excluded by comparing only where the oracle's
     # pre-activation is clear of zero.
     _, work = ops.mlp_backward(net, packed, packed_bwd, raysd, zd, d_rawd, stash, stage=1)
-    w = ops.train_views(net, P, work=work)
+    w = ops.train_views(net, n, S, work=work)
     def masked_err(got, tapname):
         want, pre = taps[tapname].grad, taps[tapname].detach()
         clear = (pre.abs() > 1e-4).float()
