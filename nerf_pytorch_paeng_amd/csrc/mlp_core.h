@@ -218,30 +218,42 @@ __device__ __forceinline__ void store_rows(const float (&h)[NB], float* row, boo
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
-// chunk q (registers 4q..4q+3 = features 8q + 4hh + {0..3}) of a B-operand register set -> its row (one 16-byte store)
+// chunk q (registers 4q..4q+3 = features 8q + 4hh + {0..3}) of a B-operand register set -> its row (one 16-byte store).
+// Unconditional: an exec-masked store costs a saveexec/branch/restore triple inside the MFMA stream.  Callers make the
+// padding lanes (sample >= S, inactive tail waves) recompute a VALID point, so their stores write the same bytes again.
 template <int NB>
-__device__ __forceinline__ void store_chunk(const float (&h)[NB], int q, float* row, bool valid) {
-    if (valid) {
-        f32x4 v; v[0] = h[4 * q + 0]; v[1] = h[4 * q + 1]; v[2] = h[4 * q + 2]; v[3] = h[4 * q + 3];
-        *(f32x4*)(row + 8 * q) = v;
-    }
+__device__ __forceinline__ void store_chunk(const float (&h)[NB], int q, float* row) {
+    f32x4 v; v[0] = h[4 * q + 0]; v[1] = h[4 * q + 1]; v[2] = h[4 * q + 2]; v[3] = h[4 * q + 3];
+    *(f32x4*)(row + 8 * q) = v;
 }
 
-// ReLU' bit masks: bit 4*(q&7)+e of word q>>3 <=> register 4q+e is > 0.  The registers are post-ReLU (+0.0 or positive,
-// relu_pinned), so "non-zero bit pattern" == "> 0": min(bits, 1) shifted into place, 2 VALU per value.
+// ReLU' bit masks.  Registers are packed in order, each word shifted left by one per value: register 4q+e lands in bit
+// 31 - (4*(q&7)+e) of word q>>3 (words always fill: 8 chunks each).  The registers are post-ReLU (+0.0 or positive,
+// relu_pinned), so "non-zero bit pattern" == "> 0": min(bits, 1) shifted in, 2 VALU per value.  Pinned with asm volatile:
+// written in C++, hipcc defers all 128 packs of a layer to the end of the GEMM (~2200 exposed cycles per layer).
+template <int NB>
+__device__ __forceinline__ void mask_bits_chunk(const float (&h)[NB], int q, unsigned (&bits)[4]) {   // 4 independent VALU
+#pragma unroll
+    for (int e = 0; e < 4; ++e) asm volatile("v_min_u32 %0, 1, %1" : "=v"(bits[e]) : "v"(h[4 * q + e]));
+}
+template <int NW>
+__device__ __forceinline__ void mask_merge_chunk(const unsigned (&bits)[4], int q, unsigned (&mw)[NW]) {   // depth-3 tree, 4 VALU
+    unsigned t01, t23;
+    asm volatile("v_lshl_or_b32 %0, %1, 1, %2" : "=v"(t01) : "v"(bits[0]), "v"(bits[1]));
+    asm volatile("v_lshl_or_b32 %0, %1, 1, %2" : "=v"(t23) : "v"(bits[2]), "v"(bits[3]));
+    asm volatile("v_lshl_or_b32 %0, %1, 2, %2" : "=v"(t01) : "v"(t01), "v"(t23));
+    asm volatile("v_lshl_or_b32 %0, %0, 4, %1" : "+v"(mw[q >> 3]) : "v"(t01));
+}
 template <int NB, int NW>
 __device__ __forceinline__ void mask_pack_chunk(const float (&h)[NB], int q, unsigned (&mw)[NW]) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const unsigned ubits = __float_as_uint(h[4 * q + e]);
-        const unsigned bit = ubits < 1u ? ubits : 1u;
-        mw[q >> 3] |= bit << (4 * (q & 7) + e);
-    }
+    unsigned bits[4];
+    mask_bits_chunk(h, q, bits);
+    mask_merge_chunk(bits, q, mw);
 }
-// register 4q+e masked by its bit: sign-extend the 1-bit field to 0 / ~0 and AND the float's bits (2 VALU)
+// register 4q+e masked by its bit: move the bit to the sign, smear it to 0 / ~0 and AND the float's bits
 template <int NW>
 __device__ __forceinline__ float mask_apply(float v, int q, int e, const unsigned (&mw)[NW]) {
-    const int m = ((int)(mw[q >> 3] << (31 - (4 * (q & 7) + e)))) >> 31;
+    const int m = ((int)(mw[q >> 3] << (4 * (q & 7) + e))) >> 31;
     return __uint_as_float(__float_as_uint(v) & (unsigned)m);
 }
 

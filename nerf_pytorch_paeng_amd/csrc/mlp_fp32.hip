@@ -231,9 +231,11 @@ void mlp_fp32_kernel(const MlpArgs a) {
             if constexpr (STASH) {
                 float* row = a.stash_h + ((long long)(l - 1) * a.stash_rows + out_idx) * W + 4 * hh;
                 unsigned mw[4] = {0u, 0u, 0u, 0u};
+                unsigned mb[4];
                 auto hook = [&](int kq, int t) __attribute__((always_inline)) {
-                    if (t == NT - 1) store_chunk(h, kq, row, valid);
-                    else if (t == NT - 2) mask_pack_chunk(h, kq, mw);
+                    if (t == NT - 1) store_chunk(h, kq, row);
+                    else if (t == NT - 2) mask_merge_chunk(mb, kq, mw);
+                    else if (t == NT - 3) mask_bits_chunk(h, kq, mb);
                 };
                 gemm_part<NT, HN, NT, AL>(acc, h, aq, smem, ring, lane, hook);
                 if (wave_active) {
@@ -253,9 +255,11 @@ void mlp_fp32_kernel(const MlpArgs a) {
         if constexpr (STASH) {
             float* row = a.stash_h + ((long long)(a.D - 1) * a.stash_rows + out_idx) * W + 4 * hh;
             unsigned mw[4] = {0u, 0u, 0u, 0u};
+            unsigned mb[4];
             auto hook = [&](int kq, int t) __attribute__((always_inline)) {
-                if (t == NT - 1) store_chunk(h, kq, row, valid);
-                else if (t == NT - 2) mask_pack_chunk(h, kq, mw);
+                if (t == NT - 1) store_chunk(h, kq, row);
+                else if (t == NT - 2) mask_merge_chunk(mb, kq, mw);
+                else if (t == NT - 3) mask_bits_chunk(h, kq, mb);
             };
             gemm_part<NT, HN, NT / 2, AL>(acc, h, aq, smem, ring, lane, hook);
             if (wave_active) {
@@ -273,7 +277,7 @@ void mlp_fp32_kernel(const MlpArgs a) {
             if constexpr (STASH) {
                 float* row = a.stash_f + out_idx * W + 4 * hh;
                 auto hook = [&](int kq, int t) __attribute__((always_inline)) {
-                    if (t == NT / 2 - 1) store_chunk(h, kq, row, valid);
+                    if (t == NT / 2 - 1) store_chunk(h, kq, row);
                 };
                 gemm_part<NT / 2, HN, NT, AL>(acc, h, aq, smem, ring, lane, hook);
             } else {

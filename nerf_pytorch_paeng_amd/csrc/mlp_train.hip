@@ -102,8 +102,8 @@ void mlp_dgrad_kernel(const DgradArgs a) {
         const int sample = (int)(wt - ray * a.tpr) * 32 + col;
         const bool valid = wave_active && sample < a.S;
         const long long idx = ray * a.S + (sample < a.S ? sample : a.S - 1);
-        f32x4 dr = *(const f32x4*)(a.d_raw + idx * 4);
-        if (!valid) { dr[0] = 0.f; dr[1] = 0.f; dr[2] = 0.f; dr[3] = 0.f; }
+        // padding lanes (sample >= S) and inactive tail waves recompute a valid point: their row stores rewrite the same bytes
+        const f32x4 dr = *(const f32x4*)(a.d_raw + idx * 4);
         const u32x2 mgv = *(const u32x2*)(a.mask_g + (wt * 64 + lane) * 2);
         u32x4 mhv = *(const u32x4*)(a.mask_h + (((long long)(a.D - 1) * a.n_wtiles + wt) * 64 + lane) * 4);
 
@@ -130,7 +130,7 @@ void mlp_dgrad_kernel(const DgradArgs a) {
         acc_zero<NT>(acc);
         {
             float* row = a.delta_d + idx * (W / 2) + 4 * hh;
-            auto hook = [&](int kq, int t) __attribute__((always_inline)) { if (t == NT - 1) store_chunk(h2, kq, row, valid); };
+            auto hook = [&](int kq, int t) __attribute__((always_inline)) { if (t == NT - 1) store_chunk(h2, kq, row); };
             gemm_part<NT, HN / 2, NT, AL>(acc, h2, aq, smem, ring, lane, hook);
         }
         acc_to_b<NT, false>(acc, h);
@@ -138,7 +138,7 @@ void mlp_dgrad_kernel(const DgradArgs a) {
         acc_zero<NT>(acc);
         {
             float* row = a.delta_f + idx * W + 4 * hh;
-            auto hook = [&](int kq, int t) __attribute__((always_inline)) { if (t == NT - 1) store_chunk(h, kq, row, valid); };
+            auto hook = [&](int kq, int t) __attribute__((always_inline)) { if (t == NT - 1) store_chunk(h, kq, row); };
             gemm_part<NT, HN, NT, AL>(acc, h, aq, smem, ring, lane, hook);
         }
         // ---- trunk, last layer first ----
@@ -160,7 +160,7 @@ void mlp_dgrad_kernel(const DgradArgs a) {
                 break;
             }
             acc_zero<NT>(acc);
-            auto hook = [&](int kq, int t) __attribute__((always_inline)) { if (t == NT - 1) store_chunk(h, kq, row, valid); };
+            auto hook = [&](int kq, int t) __attribute__((always_inline)) { if (t == NT - 1) store_chunk(h, kq, row); };
             gemm_part<NT, HN, NT, AL>(acc, h, aq, smem, ring, lane, hook);          // W_l[:, h-block]^T delta_l
         }
     }
@@ -202,7 +202,6 @@ void wgrad_big_kernel(const WgradArgs a) {
     const bool aok = m0 + 4 * i < a.M, bok = n0 + 4 * i < a.N;
     const float* abase = a.dlt + m0 + 4 * i;
     const float* bbase = a.x + n0 + 4 * i;
-    const f32x4* zp = (const f32x4*)g_zero16;
 
     f32x16 acc[4][4];
 #pragma unroll
@@ -213,32 +212,48 @@ void wgrad_big_kernel(const WgradArgs a) {
             for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.0f;
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
 
-    f32x4 ca[U], cb[U], na[U], nb[U];
-    auto load = [&](long long p, f32x4 (&A)[U], f32x4 (&B)[U]) __attribute__((always_inline)) {
+    // Main loop: whole groups of 2U points, no masking, one running pointer per operand (masked-off lanes walk the zero
+    // buffer with stride 0).  Three-stage software pipeline, and the two loads of a k-step are issued right behind the 16
+    // MFMAs of the same k-step of the CURRENT stage: left to itself hipcc puts all address arithmetic and loads of an
+    // iteration in one block in front of the 96 MFMAs, and the matrix pipe idles ~15% of the time (PMC: 80.7% busy).
+    // The pipeline reads up to four groups past the slice end: rows of the next slice, or (last slice) of the padding
+    // train_layout() leaves behind every operand; those values are zeroed before they are multiplied.
+    const long long stride_a = aok ? (long long)a.ldd * 2 : 0, stride_b = bok ? (long long)a.ldx * 2 : 0;     // floats per k-step
+    const float* pa = aok ? abase + (pb + kh) * a.ldd : g_zero16;
+    const float* pbp = bok ? bbase + (pb + kh) * a.ldx : g_zero16;
+    f32x4 ca[U], cb[U], na[U], nb[U], fa[U], fb[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { ca[u] = *(const f32x4*)pa; cb[u] = *(const f32x4*)pbp; pa += stride_a; pbp += stride_b; }
+#pragma unroll
+    for (int u = 0; u < U; ++u) { na[u] = *(const f32x4*)pa; nb[u] = *(const f32x4*)pbp; pa += stride_a; pbp += stride_b; }
+    // one group: multiply stage (A, B) while stage (FA, FB) is being requested.  The three register sets rotate by NAME
+    // (loop unrolled by 3), never by copy: a copy of a just-requested set forces s_waitcnt vmcnt(0) at the loop head,
+    // i.e. a prefetch distance of a fraction of one group instead of two.  Rows at or past the slice end are zeroed in
+    // BOTH operands (the other side may hold anything, 0 x NaN = NaN), 8 v_cndmask per 16 MFMAs; that keeps the loop
+    // free of remainder paths (which cost 1.4 KB of scratch per lane when written as branches).
+    int rows_left = (int)(pe - pb) - kh;                  // this lane half's rows: 0, 2, 4, ... (kh = 0) or 1, 3, ... (kh = 1)
+    auto step = [&](f32x4 (&A)[U], f32x4 (&B)[U], f32x4 (&FA)[U], f32x4 (&FB)[U]) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const long long row = p + 2 * u + kh;
-            const bool ok = row < pe;
-            const f32x4* qa = (ok && aok) ? (const f32x4*)(abase + row * a.ldd) : zp;
-            const f32x4* qb = (ok && bok) ? (const f32x4*)(bbase + row * a.ldx) : zp;
-            A[u] = *qa;
-            B[u] = *qb;
-        }
-    };
-    load(pb, ca, cb);
-    for (long long p = pb; p < pe; p += 2 * U) {
-        load(p + 2 * U, na, nb);          // past the slice end: zeros
+            const bool ok = 2 * u < rows_left;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            bsum += ca[u];
+            for (int e = 0; e < 4; ++e) { A[u][e] = ok ? A[u][e] : 0.0f; B[u][e] = ok ? B[u][e] : 0.0f; }
+            bsum += A[u];
 #pragma unroll
             for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
                 for (int tn = 0; tn < 4; ++tn)
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[u][tm], cb[u][tn], acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[u][tm], B[u][tn], acc[tm][tn], 0, 0, 0);
+            FA[u] = *(const f32x4*)pa; FB[u] = *(const f32x4*)pbp; pa += stride_a; pbp += stride_b;
+            __builtin_amdgcn_sched_barrier(0);
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u) { ca[u] = na[u]; cb[u] = nb[u]; }
+        rows_left -= 2 * U;
+    };
+    const long long n_groups = (pe - pb + 2 * U - 1) / (2 * U);
+    for (long long g = 0; g < n_groups; g += 3) {           // a multiple of 3 groups; surplus groups multiply zeros
+        step(ca, cb, fa, fb);
+        step(na, nb, ca, cb);
+        step(fa, fb, na, nb);
     }
     // D[i'][j]: i' = (r&3) + 8*(r>>2) + 4*kh is the A-side lane index, j = lane & 31 the B-side one
     float* out = a.partial + (size_t)blockIdx.x * a.Mp * a.Np;
@@ -355,6 +370,8 @@ static int num_cus_t() {
 }
 
 static inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+// wgrad_big_kernel's load pipeline runs up to 5 groups x 12 rows x 1 KiB past the end of an operand
+constexpr size_t WGRAD_OVERRUN_PAD = 128 * 1024;
 
 constexpr size_t WGRAD_PARTIAL_FLOATS = (size_t)256 * 256 * 256 + (size_t)256 * 256;   // 256 slices of a 256x256 block + bias rows
 
@@ -369,14 +386,14 @@ int train_layout(const mi_nerf_net* net, int64_t n_rays, int S, mi_nerf_train_la
     size_t off = 0;
     L->stash_h = off; off += al256(D * p * W * 4);
     L->stash_f = off; off += al256(p * W * 4);
-    L->stash_g = off; off += al256(p * (W / 2) * 4);
+    L->stash_g = off; off += al256(p * (W / 2) * 4) + WGRAD_OVERRUN_PAD;
     L->mask_h = off;  off += al256(D * n_wtiles * 64 * 16);
     L->mask_g = off;  off += al256(n_wtiles * 64 * 8);
     L->stash_bytes = off;
     off = 0;
     L->delta_h = off; off += al256(D * p * W * 4);
     L->delta_f = off; off += al256(p * W * 4);
-    L->delta_d = off; off += al256(p * (W / 2) * 4);
+    L->delta_d = off; off += al256(p * (W / 2) * 4) + WGRAD_OVERRUN_PAD;
     L->emb = off;     off += al256(p * in_all * 4);
     L->partial = off; off += al256(WGRAD_PARTIAL_FLOATS * 4);
     L->work_bytes = off;
@@ -395,13 +412,13 @@ static int run_wgrad(const float* dlt, int ldd, int M, const float* x, int ldx, 
     const int bm = big ? 256 : 64, bn = big ? 256 : 64;
     const int by = (M + bm - 1) / bm, bz = (N + bn - 1) / bn;
     a.Mp = by * bm; a.Np = bz * bn;
-    // big: one workgroup per CU owns all registers; small: ~8 workgroups per CU hide the HBM latency by occupancy
-    int slices = (big ? num_cus_t() : 8 * num_cus_t()) / (by * bz);
+    // big: one workgroup per CU owns all registers; small: ~4 workgroups per CU hide the HBM latency by occupancy
+    int slices = (big ? num_cus_t() : 4 * num_cus_t()) / (by * bz);
     const size_t per_slice = (size_t)a.Mp * a.Np + a.Mp;
     if ((size_t)slices * per_slice > WGRAD_PARTIAL_FLOATS) slices = (int)(WGRAD_PARTIAL_FLOATS / per_slice);
     if (slices < 1) slices = 1;
     long long pps = (P + slices - 1) / slices;
-    pps = (pps + 15) / 16 * 16;
+    pps = (pps + 11) / 12 * 12;          // whole load groups (2 x U points) in every slice but the last
     slices = (int)((P + pps - 1) / pps);
     MN_CHECK_ARG((size_t)slices * per_slice <= WGRAD_PARTIAL_FLOATS, "internal: wgrad partial buffer too small");
     a.pps = (int)pps;
