@@ -240,7 +240,17 @@ def main():
                 dt = time.perf_counter() - t0
                 reps.append(dt)
                 spent += dt
+        train_cpu = None
+        if train is not None:                                   # same port, one training step (autograd) on a bounded sample
+            n_tr = 256
+            psd = {k: torch.as_tensor(v).clone().float().requires_grad_(True) for k, v in sd.items()}
+            tgt = torch.rand(n_tr, 3, generator=torch.Generator().manual_seed(0))
+            t0 = time.perf_counter()
+            ref = R.render_rays(rc[:n_tr], psd, pcfg, tc[:n_tr], uc[:n_tr])
+            (torch.mean((ref["rgb_c"] - tgt) ** 2) + torch.mean((ref["rgb_f"] - tgt) ** 2)).backward()
+            train_cpu = round(n_tr / (time.perf_counter() - t0), 1)
         cpu = {"value": round(n_cpu / float(np.median(reps)), 1), "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+               "train_rays_per_s": train_cpu,
                "sample": f"oracle/restate.py render_rays (torch CPU fp32) on the first {n_cpu} rays of the same 4096-ray batch, "
                          f"median of {len(reps)} reps"}
 
