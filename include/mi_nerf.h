@@ -201,6 +201,26 @@ int mi_nerf_mlp_backward(const mi_nerf_net* net, const void* packed_dev, const v
                          const float* z_dev, int64_t n_rays, int S, const float* d_raw_dev, const void* stash_dev,
                          void* work_dev, size_t work_bytes, float* grads_dev, int stage, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Either side of the path in the reference's callers.  HBM-bound streaming ops.
+ * `scratch`: caller-allocated device buffer of at least MI_NERF_REDUCE_SCRATCH_BYTES.
+ * ---------------------------------------------------------------------------------------------- */
+#define MI_NERF_REDUCE_SCRATCH_BYTES 8192
+/* img2mse + mse2psnr (utils.py:18-23; test.py:64-68): out2_dev = { mean((pred-target)^2), -10 log10(mse) } over n floats */
+int mi_nerf_image_metrics(const float* pred_dev, const float* target_dev, int64_t n, float* out2_dev, void* scratch_dev,
+                          size_t scratch_bytes, void* stream);
+/* np.nanmax (test.py:56, test.py:157): maximum ignoring NaN (NaN if every element is NaN) */
+int mi_nerf_nanmax(const float* x_dev, int64_t n, float* out_dev, void* scratch_dev, size_t scratch_bytes, void* stream);
+/* to8b(x) or to8b(x / divisor_dev[0]) (utils.py:15; test.py:55-56): (255 * clip(v, 0, 1)).astype(uint8); divisor_dev may be NULL */
+int mi_nerf_to8b(const float* x_dev, int64_t n, const float* divisor_dev, uint8_t* out_dev, void* stream);
+/* Global-batch precompute (main.py:92-101): for n_img training images, rays_rgb [n_img*H*W, 3, 3] = (origin, direction,
+ * pixel) per ray; get_rays_np (rays.py:7-17) for every pose in one launch.  poses [n_img,12] row-major 3x4 c2w,
+ * images [n_img,H,W,3], k4 = {fx, fy, cx, cy}. */
+int mi_nerf_rays_rgb(int W, int H, const float k4[4], const float* poses_dev, const float* images_dev, int64_t n_img,
+                     float* rays_rgb_dev, void* stream);
+/* np.random.shuffle(rays_rgb) (main.py:102; utils.py:47-52): dst[i] = src[perm[i]], rows of row_floats floats; perm int64 */
+int mi_nerf_permute_rows(const float* src_dev, const int64_t* perm_dev, int64_t n, int row_floats, float* dst_dev, void* stream);
+
 /* Timing hook used by bench.py: average device time (ms) of `iters` back-to-back launches of the fused MLP
  * kernel on `stream`, measured with hipEvents recorded on that same stream (torch.cuda.Event only sees
  * torch's current stream).  Synchronises the stream. */

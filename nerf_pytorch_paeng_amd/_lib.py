@@ -84,6 +84,11 @@ SIGNATURES = {
     "mi_nerf_train_layout_query": (_I, [_NETP, _I64, _I, C.POINTER(TrainLayout)]),
     "mi_nerf_mlp_rays_train": (_I, [_NETP, _P, _P, _P, _I64, _I, _P, _P, _SZ, _P]),
     "mi_nerf_mlp_backward": (_I, [_NETP, _P, _P, _P, _P, _I64, _I, _P, _P, _P, _SZ, _P, _I, _P]),
+    "mi_nerf_image_metrics": (_I, [_P, _P, _I64, _P, _P, _SZ, _P]),
+    "mi_nerf_nanmax": (_I, [_P, _I64, _P, _P, _SZ, _P]),
+    "mi_nerf_to8b": (_I, [_P, _I64, _P, _P, _P]),
+    "mi_nerf_rays_rgb": (_I, [_I, _I, C.POINTER(_F), _P, _P, _I64, _P, _P]),
+    "mi_nerf_permute_rows": (_I, [_P, _P, _I64, _I, _P, _P]),
     "mi_nerf_time_mlp_rays": (_I, [_NETP, _P, _P, _P, _I64, _I, _P, _I, _I, C.POINTER(_F), _P]),
     "mi_nerf_selftest_mfma": (_I, [_P]),
 }

@@ -35,6 +35,11 @@ int pack_apply(const int32_t*, const float*, size_t, void*, hipStream_t);
 int pack_bwd_fp32(const mi_nerf_net*, const mi_nerf_params*, void*, size_t);
 size_t packed_bytes_bwd(const mi_nerf_net*);
 int pack_map(const mi_nerf_net*, int, int32_t*, size_t);
+int frames_image_metrics(const float*, const float*, int64_t, float*, void*, size_t, hipStream_t);
+int frames_nanmax(const float*, int64_t, float*, void*, size_t, hipStream_t);
+int frames_to8b(const float*, int64_t, const float*, unsigned char*, hipStream_t);
+int frames_rays_rgb(int, int, const float*, const float*, const float*, int64_t, float*, hipStream_t);
+int frames_permute_rows(const float*, const int64_t*, int64_t, int, float*, hipStream_t);
 int stage_make_o_d(int, int, const float*, const float*, int, int, float*, float*, hipStream_t);
 int stage_make_o_d_pixels(int, int, const float*, const float*, const int64_t*, int64_t, float*, float*, hipStream_t);
 int stage_ndc(int, int, float, float, const float*, int64_t, const float*, int64_t, int64_t, float*, float*, hipStream_t);
@@ -219,6 +224,22 @@ int mi_nerf_mlp_backward(const mi_nerf_net* net, const void* packed, const void*
                          int stage, void* st) {
     if (int rc = check_net_basic(net)) return rc;
     return mlp_backward_fp32(net, packed, packed_bwd, rays, z, n_rays, S, d_raw, stash, work, work_bytes, grads, stage, (hipStream_t)st);
+}
+
+int mi_nerf_image_metrics(const float* pred, const float* target, int64_t n, float* out2, void* scratch, size_t scratch_bytes, void* st) {
+    return frames_image_metrics(pred, target, n, out2, scratch, scratch_bytes, (hipStream_t)st);
+}
+int mi_nerf_nanmax(const float* x, int64_t n, float* out, void* scratch, size_t scratch_bytes, void* st) {
+    return frames_nanmax(x, n, out, scratch, scratch_bytes, (hipStream_t)st);
+}
+int mi_nerf_to8b(const float* x, int64_t n, const float* divisor, uint8_t* out, void* st) {
+    return frames_to8b(x, n, divisor, out, (hipStream_t)st);
+}
+int mi_nerf_rays_rgb(int W, int H, const float k4[4], const float* poses, const float* images, int64_t n_img, float* out, void* st) {
+    return frames_rays_rgb(W, H, k4, poses, images, n_img, out, (hipStream_t)st);
+}
+int mi_nerf_permute_rows(const float* src, const int64_t* perm, int64_t n, int row_floats, float* dst, void* st) {
+    return frames_permute_rows(src, perm, n, row_floats, dst, (hipStream_t)st);
 }
 
 size_t mi_nerf_render_workspace_bytes(const mi_nerf_render_cfg* cfg, int64_t n_rays) {

@@ -1,0 +1,255 @@
+"""The callers either side of the path, kept on the device.
+
+* ``test`` / ``render`` -- counterparts of the reference's eval and video harness (test.py:17-108, 111-174):
+  checkpoint ingest (``model_state_dict`` of a reference ``.pth.tar``), one ``make_o_d`` +
+  ``batchify_rays_and_render_by_chunk`` per pose, MSE/PSNR against ground truth, 8-bit frames.  Metrics and the
+  8-bit conversion run as device kernels (``mi_nerf_image_metrics``, ``mi_nerf_nanmax``, ``mi_nerf_to8b``); the only
+  device->host copies are the finished uint8 frames and two floats per frame.  SSIM / LPIPS come from a third-party
+  package the reference imports (IQA_pytorch) and are not part of this path: they are reported as ``None``.
+* ``global_batch`` / ``GetterRayBatchIdx`` -- the global-batch ray precompute and epoch shuffle (main.py:92-106,
+  utils.py:45-62) as one ray-generation launch over all training images and a device-side row permutation, instead
+  of numpy on the host followed by a 2.3 GB upload.
+* ``sample_rays_and_pixel`` -- per-image ray/pixel sampling (rays.py:36-64); rays are generated for the selected
+  pixels only.
+* ``get_render_pose`` / ``pose_spherical`` -- the 360-degree camera path (dataset/render_pose.py:28-43), built on the
+  host once and uploaded once.
+
+PNG output uses a 30-line zlib encoder (imageio, which the reference uses, is not a dependency of this path).
+"""
+from __future__ import annotations
+
+import os
+import struct
+import zlib
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import nerf_process as NP
+from . import ops
+from ._lib import MiNerfError, as_f32_dev
+from .rays import make_o_d
+
+
+# ---------------------------------------------------------------------------------------------------
+# small host utilities
+# ---------------------------------------------------------------------------------------------------
+def write_png(path: str, img: np.ndarray) -> None:
+    """uint8 [H,W], [H,W,1] or [H,W,3] -> PNG (8-bit grey or RGB)."""
+    a = np.ascontiguousarray(img)
+    if a.dtype != np.uint8:
+        raise MiNerfError(f"write_png wants uint8, got {a.dtype}")
+    if a.ndim == 3 and a.shape[2] == 1:
+        a = a[:, :, 0]
+    if a.ndim == 2:
+        color, raw = 0, a
+    elif a.ndim == 3 and a.shape[2] == 3:
+        color, raw = 2, a.reshape(a.shape[0], -1)
+    else:
+        raise MiNerfError(f"write_png: unsupported shape {a.shape}")
+    h, w = a.shape[0], a.shape[1]
+    rows = np.concatenate([np.zeros((h, 1), np.uint8), raw], axis=1).tobytes()        # filter byte 0 per scanline
+
+    def chunk(tag: bytes, data: bytes) -> bytes:
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, color, 0, 0, 0))
+                + chunk(b"IDAT", zlib.compress(rows, 6)) + chunk(b"IEND", b""))
+
+
+def load_checkpoint(path: str, model: Optional[torch.nn.Module] = None) -> Dict:
+    """torch.load of a reference checkpoint ({'idx', 'model_state_dict', 'optimizer_state_dict'}, train.py:105-114);
+    loads ``model_state_dict`` into ``model`` when given (test.py:20-21)."""
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    if "model_state_dict" not in ck:
+        raise MiNerfError(f"{path}: no 'model_state_dict' (keys: {sorted(ck)[:8]})")
+    if model is not None:
+        model.load_state_dict(ck["model_state_dict"])
+    return ck
+
+
+def _ckpt_path(log_dir: str, exp_name: str, idx) -> str:
+    return os.path.join(log_dir, exp_name, f"{exp_name}_{idx}.pth.tar")                 # test.py:20, train.py:112-114
+
+
+def pose_spherical(theta: float, phi: float, radius: float) -> torch.Tensor:
+    """dataset/render_pose.py:28-34 with the same fp32 matrix chain."""
+    def t32(rows):
+        return torch.tensor(np.array(rows), dtype=torch.float32)
+    trans = t32([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, radius], [0, 0, 0, 1]])
+    ph = phi / 180.0 * np.pi
+    rot_phi = t32([[1, 0, 0, 0], [0, np.cos(ph), -np.sin(ph), 0], [0, np.sin(ph), np.cos(ph), 0], [0, 0, 0, 1]])
+    th = theta / 180.0 * np.pi
+    rot_theta = t32([[np.cos(th), 0, -np.sin(th), 0], [0, 1, 0, 0], [np.sin(th), 0, np.cos(th), 0], [0, 0, 0, 1]])
+    c2w = rot_theta @ (rot_phi @ trans)
+    return t32([[-1, 0, 0, 0], [0, 0, 1, 0], [0, 1, 0, 0], [0, 0, 0, 1]]) @ c2w
+
+
+def get_render_pose(n_angle: int = 1, single_angle: float = -1, phi: float = -30.0, nf: float = 4.0, device=None) -> torch.Tensor:
+    """dataset/render_pose.py:37-43 -> [n, 4, 4]; uploaded once when ``device`` is given."""
+    if not n_angle == 1 and single_angle == -1:
+        poses = torch.stack([pose_spherical(a, phi, nf) for a in np.linspace(-180, 180, n_angle + 1)[:-1]], 0)
+    else:
+        poses = pose_spherical(single_angle, phi, nf).unsqueeze(0)
+    return poses.to(device) if device is not None else poses
+
+
+# ---------------------------------------------------------------------------------------------------
+# eval / video harness
+# ---------------------------------------------------------------------------------------------------
+def _render_pose(model, posenc, K, pose, hw, opts):
+    img_h, img_w = hw
+    rays_o, rays_d = make_o_d(img_w, img_h, K, pose[:3, :4])
+    rgb_c, disp_c, rgb_f, disp_f = NP.batchify_rays_and_render_by_chunk(rays_o, rays_d, model, posenc, img_h, img_w, K, opts)
+    return (rgb_c, disp_c) if int(opts.N_samples_f) == 0 else (rgb_f, disp_f)             # test.py:42-47
+
+
+def test(idx, i_test, posenc, model, test_imgs, gt_intrinsic, gt_extrinsic, hw, opts, *, log_dir: Optional[str] = None,
+         save_dir: Optional[str] = None, keep_frames: bool = False) -> Dict:
+    """Counterpart of test.py:17-108.  ``log_dir`` given: load ``{log_dir}/{exp_name}/{exp_name}_{idx}.pth.tar`` first
+    (test.py:20-21).  ``save_dir`` given: write ``NNN.png``, ``NNN_disp.png`` and ``_result.txt`` like the reference.
+    Returns per-frame loss / PSNR (Python floats), best / mean PSNR, and the uint8 frames when ``keep_frames``."""
+    if isinstance(model, torch.nn.Module):
+        model.eval()
+        if log_dir is not None:
+            load_checkpoint(_ckpt_path(log_dir, opts.exp_name, idx), model)
+    if save_dir is not None:
+        os.makedirs(save_dir, exist_ok=True)
+    img_h, img_w = hw
+    dev = next(model.parameters()).device if isinstance(model, torch.nn.Module) else model.device
+    losses: List[float] = []
+    psnrs: List[float] = []
+    frames = []
+    with torch.no_grad():
+        for i, pose in enumerate(gt_extrinsic):
+            pose = as_f32_dev(pose, dev)
+            pred_rgb, pred_disp = _render_pose(model, posenc, gt_intrinsic, pose, hw, opts)
+            target = as_f32_dev(test_imgs[i], pred_rgb.device).reshape(-1, 3)             # test.py:63
+            m = ops.image_metrics(pred_rgb, target)                                       # img2mse, mse2psnr: test.py:65-67
+            rgb8 = ops.to8b(pred_rgb).reshape(img_h, img_w, 3)                            # test.py:55
+            disp8 = ops.to8b(pred_disp, ops.nanmax(pred_disp)).reshape(img_h, img_w, 1)   # test.py:56
+            mse, psnr = (float(v) for v in m.cpu())
+            losses.append(mse)
+            psnrs.append(psnr)
+            if save_dir is not None or keep_frames:
+                rgb_np, disp_np = rgb8.cpu().numpy(), disp8.cpu().numpy()
+                if save_dir is not None:
+                    write_png(os.path.join(save_dir, f"{i:03d}.png"), rgb_np)
+                    write_png(os.path.join(save_dir, f"{i:03d}_disp.png"), disp_np)
+                if keep_frames:
+                    frames.append((rgb_np, disp_np))
+    best = int(np.argmax(psnrs)) if psnrs else -1
+    res = {"loss": losses, "psnr": psnrs, "ssim": None, "lpips": None, "best_idx": best,
+           "best_psnr": psnrs[best] if psnrs else None, "mean_psnr": float(np.mean(psnrs)) if psnrs else None}
+    if keep_frames:
+        res["frames"] = frames
+    if save_dir is not None:                                                              # test.py:92-108
+        with open(os.path.join(save_dir, "_result.txt"), "w") as f:
+            for i in range(len(losses)):
+                f.write(f"idx:{i}\tloss:{losses[i]}\tpsnr:{psnrs[i]}\tssim:n/a\tlpips:n/a\n")
+            f.write(f"\nBest Value ) PSNR : {res['best_psnr']}\tSSIM : n/a\tLPIPS : n/a\n")
+            f.write(f"Mean Value ) PSNR : {res['mean_psnr']}\tSSIM : n/a\tLPIPS : n/a")
+    return res
+
+
+def render(idx, posenc, model, gt_intrinsic, render_pose, hw, opts, *, log_dir: Optional[str] = None, save_dir: Optional[str] = None):
+    """Counterpart of test.py:111-174: renders every pose of ``render_pose`` (for blender/custom data the spherical path
+    from opts, test.py:119-124) and returns ``(rgbs uint8 [N,H,W,3], disps uint8 [N,H,W])`` -- the arrays the reference
+    hands to imageio.mimwrite (test.py:166-172).  ``save_dir``: also write ``{i}_rgb.png`` / ``{i}_disp.png``."""
+    dev = next(model.parameters()).device if isinstance(model, torch.nn.Module) else model.device
+    if getattr(opts, "data_type", None) in ("blender", "custom"):
+        render_pose = get_render_pose(n_angle=opts.n_angle, single_angle=opts.single_angle, phi=opts.phi, nf=opts.nf)
+    poses = torch.as_tensor(np.asarray(render_pose) if not isinstance(render_pose, torch.Tensor) else render_pose, dtype=torch.float32).to(dev)
+    if isinstance(model, torch.nn.Module):
+        model.eval()
+        if log_dir is not None:
+            load_checkpoint(_ckpt_path(log_dir, opts.exp_name, idx), model)
+    if save_dir is not None:
+        os.makedirs(save_dir, exist_ok=True)
+    img_h, img_w = hw
+    n = poses.shape[0]
+    rgbs = torch.empty(n, img_h, img_w, 3, dtype=torch.uint8, device=dev)
+    disps = torch.empty(n, img_h, img_w, dtype=torch.uint8, device=dev)
+    with torch.no_grad():
+        for i in range(n):
+            rgb, disp = _render_pose(model, posenc, gt_intrinsic, poses[i], hw, opts)
+            rgbs[i] = ops.to8b(rgb).reshape(img_h, img_w, 3)                              # to8b(rgbs), test.py:167
+            disps[i] = ops.to8b(disp, ops.nanmax(disp)).reshape(img_h, img_w)             # disp / nanmax, test.py:156,168
+    rgbs_np, disps_np = rgbs.cpu().numpy(), disps.cpu().numpy()                           # one copy for the whole clip
+    if save_dir is not None:
+        for i in range(n):
+            write_png(os.path.join(save_dir, f"{i}_rgb.png"), rgbs_np[i])
+            write_png(os.path.join(save_dir, f"{i}_disp.png"), disps_np[i])
+    return rgbs_np, disps_np
+
+
+# ---------------------------------------------------------------------------------------------------
+# training data staging
+# ---------------------------------------------------------------------------------------------------
+class GetterRayBatchIdx:
+    """Epoch cursor over the shuffled global batch (utils.py:45-62), on the device.  ``__call__(batch)`` returns
+    ``(i_batch, rays_rgb, epoch)`` exactly like the reference; the caller slices ``rays_rgb[i_batch - B : i_batch]``
+    (train.py:27-29)."""
+
+    def __init__(self, rays_rgb: torch.Tensor, generator: Optional[torch.Generator] = None):
+        self.rays_rgb = rays_rgb
+        self.epoch = 0
+        self.i_batch = 0
+        self._gen = generator
+
+    def shuffle_ray_idx(self, batch_size: int) -> None:
+        n = self.rays_rgb.shape[0]
+        perm = torch.randperm(n, device=self.rays_rgb.device, generator=self._gen)        # utils.py:49
+        self.rays_rgb = ops.permute_rows(self.rays_rgb, perm)                             # utils.py:50
+        self.i_batch = batch_size
+        self.epoch += 1
+
+    def __call__(self, batch_size: int):
+        self.i_batch += batch_size
+        if self.i_batch >= self.rays_rgb.shape[0]:
+            self.shuffle_ray_idx(batch_size)
+        return self.i_batch, self.rays_rgb, self.epoch
+
+
+def global_batch(images, gt_intrinsic, gt_extrinsic, i_train: Sequence[int], hw, device, generator: Optional[torch.Generator] = None,
+                 shuffle: bool = True) -> GetterRayBatchIdx:
+    """main.py:92-106: rays for every training image, concatenated with the pixels, flattened to [N*H*W, 3, 3], shuffled.
+    ``images`` [n_img,H,W,3] and ``gt_extrinsic`` [n_img,4,4] may live on the host: only the selected views are uploaded."""
+    img_h, img_w = hw
+    idx = torch.as_tensor(np.asarray(list(i_train)), dtype=torch.long)
+    imgs = torch.as_tensor(np.asarray(images) if not isinstance(images, torch.Tensor) else images)
+    poses = torch.as_tensor(np.asarray(gt_extrinsic) if not isinstance(gt_extrinsic, torch.Tensor) else gt_extrinsic)
+    imgs = imgs[idx.to(imgs.device)].to(device=device, dtype=torch.float32).contiguous()
+    poses = poses[idx.to(poses.device)][:, :3, :4].to(device=device, dtype=torch.float32).contiguous()
+    rr = ops.rays_rgb(img_w, img_h, gt_intrinsic, poses, imgs)
+    if shuffle:
+        rr = ops.permute_rows(rr, torch.randperm(rr.shape[0], device=rr.device, generator=generator))   # main.py:102
+    return GetterRayBatchIdx(rr, generator)
+
+
+def sample_rays_and_pixel(i, img_w, img_h, K, pose, target_img, opts, generator: Optional[torch.Generator] = None):
+    """rays.py:36-64 fused with the ``make_o_d`` that precedes it in train.py:43-45: N_rays pixels without replacement
+    (inside the centre crop while ``i < opts.precrop_iters``), rays generated for those pixels only.
+    Returns ``(rays_o [N,3], rays_d [N,3], target [N,3])``."""
+    target_img = as_f32_dev(target_img)
+    dev = target_img.device
+    if i < int(getattr(opts, "precrop_iters", 0)):
+        dH = int(img_h // 2 * opts.precrop_frac)
+        dW = int(img_w // 2 * opts.precrop_frac)
+        ys = torch.arange(img_h // 2 - dH, img_h // 2 + dH, device=dev)
+        xs = torch.arange(img_w // 2 - dW, img_w // 2 + dW, device=dev)
+    else:
+        ys = torch.arange(img_h, device=dev)
+        xs = torch.arange(img_w, device=dev)
+    n_coords = ys.numel() * xs.numel()
+    n = int(opts.N_rays)
+    if n > n_coords:
+        raise MiNerfError(f"cannot draw {n} pixels without replacement from {n_coords}")       # np.random.choice raises too
+    sel = torch.randperm(n_coords, device=dev, generator=generator)[:n]                         # rays.py:53-54
+    py, px = ys[sel // xs.numel()], xs[sel % xs.numel()]
+    pix = (py * img_w + px).contiguous()
+    rays_o, rays_d = ops.make_o_d_pixels(int(img_w), int(img_h), K, pose, pix)
+    target = target_img.reshape(-1, 3)[pix]
+    return rays_o, rays_d, target

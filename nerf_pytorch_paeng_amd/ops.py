@@ -369,6 +369,74 @@ def train_views(net: Net, n_rays: int, S: int, stash: Optional[torch.Tensor] = N
 
 
 # ------------------------------------------------------------------------------------------------
+# either side of the path: frame metrics, 8-bit conversion, global-batch staging
+# ------------------------------------------------------------------------------------------------
+REDUCE_SCRATCH_BYTES = 8192
+
+
+def image_metrics(pred: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    """[mse, psnr] (device tensor of 2 floats): img2mse + mse2psnr, utils.py:18-23."""
+    if pred.shape != target.shape or pred.numel() == 0:
+        raise MiNerfError(f"pred {tuple(pred.shape)} and target {tuple(target.shape)} must match and be non-empty")
+    dev = pred.device
+    out = torch.empty(2, dtype=torch.float32, device=dev)
+    scratch = torch.empty(REDUCE_SCRATCH_BYTES, dtype=torch.uint8, device=dev)
+    with _guard(dev):
+        check(lib().mi_nerf_image_metrics(dev_ptr(pred, "pred"), dev_ptr(target, "target"), pred.numel(), dev_ptr(out),
+                                          dev_ptr(scratch, "scratch", torch.uint8), scratch.numel(), stream_ptr(dev)), "mi_nerf_image_metrics")
+    return out
+
+
+def nanmax(x: torch.Tensor) -> torch.Tensor:
+    if x.numel() == 0:
+        raise MiNerfError("nanmax of an empty tensor")
+    dev = x.device
+    out = torch.empty(1, dtype=torch.float32, device=dev)
+    scratch = torch.empty(REDUCE_SCRATCH_BYTES, dtype=torch.uint8, device=dev)
+    with _guard(dev):
+        check(lib().mi_nerf_nanmax(dev_ptr(x, "x"), x.numel(), dev_ptr(out), dev_ptr(scratch, "scratch", torch.uint8), scratch.numel(),
+                                   stream_ptr(dev)), "mi_nerf_nanmax")
+    return out
+
+
+def to8b(x: torch.Tensor, divisor: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """uint8 image of x (or x / divisor[0]): utils.py:15 on the device."""
+    dev = x.device
+    out = torch.empty(x.shape, dtype=torch.uint8, device=dev)
+    with _guard(dev):
+        check(lib().mi_nerf_to8b(dev_ptr(x, "x"), x.numel(), dev_ptr(divisor, "divisor"), dev_ptr(out, "out", torch.uint8, 1), stream_ptr(dev)),
+              "mi_nerf_to8b")
+    return out
+
+
+def rays_rgb(W: int, H: int, K, poses: torch.Tensor, images: torch.Tensor) -> torch.Tensor:
+    """[n_img*H*W, 3, 3] (origin, direction, pixel) for every pixel of every image: main.py:92-101 in one launch."""
+    n_img = poses.shape[0]
+    if tuple(poses.shape[1:]) != (3, 4) or tuple(images.shape) != (n_img, H, W, 3):
+        raise MiNerfError(f"poses must be [n,3,4] and images [n,{H},{W},3]; got {tuple(poses.shape)} / {tuple(images.shape)}")
+    dev = images.device
+    k = K.detach().cpu().numpy() if isinstance(K, torch.Tensor) else np.asarray(K)
+    k4 = (C.c_float * 4)(float(np.float32(k[0][0])), float(np.float32(k[1][1])), float(np.float32(k[0][2])), float(np.float32(k[1][2])))
+    out = torch.empty(n_img * H * W, 3, 3, dtype=torch.float32, device=dev)
+    with _guard(dev):
+        check(lib().mi_nerf_rays_rgb(int(W), int(H), k4, dev_ptr(poses, "poses"), dev_ptr(images, "images"), n_img, dev_ptr(out),
+                                     stream_ptr(dev)), "mi_nerf_rays_rgb")
+    return out
+
+
+def permute_rows(src: torch.Tensor, perm: torch.Tensor) -> torch.Tensor:
+    n = src.shape[0]
+    if perm.shape != (n,):
+        raise MiNerfError(f"perm must be [{n}], got {tuple(perm.shape)}")
+    row = src.numel() // max(n, 1)
+    dst = torch.empty_like(src)
+    with _guard(src.device):
+        check(lib().mi_nerf_permute_rows(dev_ptr(src, "src"), dev_ptr(perm, "perm", torch.int64, 8), n, int(row), dev_ptr(dst), stream_ptr(src.device)),
+              "mi_nerf_permute_rows")
+    return dst
+
+
+# ------------------------------------------------------------------------------------------------
 # fused render
 # ------------------------------------------------------------------------------------------------
 def render_cfg(near: float, far: float, Sc: int, Nf: int, det: bool, bf16: bool = False) -> RenderCfg:

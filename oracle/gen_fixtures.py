@@ -110,10 +110,62 @@ def save(name, **arrays):
 
 
 # ----------------------------------------------------------------------------------------------
+def f10_callers():
+    """F10: the callers either side of the path -- utils.py metrics / 8-bit conversion /
+    epoch cursor, dataset/render_pose.py camera path, rays.get_rays_np feeding the global-batch layout of main.py:92-101."""
+    print("F10 callers")
+    import utils as ref_utils                                   # noqa: E402  (IQA_pytorch is stubbed by load_reference)
+    # dataset/__init__.py eagerly imports the disk loaders (imageio, cv2, configargparse ...): load render_pose.py by path
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_render_pose", os.path.join(REF, "dataset", "render_pose.py"))
+    rp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rp)
+    ref_poses, ref_pose_spherical = rp.get_render_pose, rp.pose_spherical
+    import rays as ref_rays
+    rs = np.random.RandomState(77)
+    f = {}
+    f["poses8"] = ref_poses(n_angle=8, single_angle=-1, phi=-30.0, nf=4.0)
+    f["pose_single"] = ref_poses(n_angle=1, single_angle=120, phi=-20.0, nf=3.5)
+    f["pose_sph"] = ref_pose_spherical(33.0, -41.0, 4.0)
+    x = np.concatenate([rs.uniform(-0.3, 1.3, 500), [0.0, 1.0, 1.0 / 255, 254.999 / 255, 0.5, -0.0]]).astype(np.float32)
+    f["to8b_in"], f["to8b_out"] = x, ref_utils.to8b(x)
+    disp = rs.uniform(0.0, 5.0, (7, 9)).astype(np.float32)
+    f["disp_in"], f["disp_max"], f["disp8"] = disp, np.nanmax(disp), ref_utils.to8b(disp / np.nanmax(disp))   # test.py:56
+    with_nan = disp.copy(); with_nan[2, 3] = np.nan; with_nan[6, 8] = np.nan
+    f["nanmax_in"], f["nanmax_out"] = with_nan, np.nanmax(with_nan)
+    pred = torch.from_numpy(rs.uniform(0, 1, (300, 3)).astype(np.float32))
+    tgt = torch.from_numpy(rs.uniform(0, 1, (300, 3)).astype(np.float32))
+    mse = ref_utils.img2mse(pred, tgt)
+    f["metric_pred"], f["metric_target"], f["metric_mse"], f["metric_psnr"] = pred, tgt, mse, ref_utils.mse2psnr(mse)
+    # global batch: main.py:95-101 executed on the reference's get_rays_np (the statements are inline in main_worker)
+    H, W, n_img = 6, 5, 3
+    K = np.array([[7.5, 0, 2.5], [0, 7.5, 3.0], [0, 0, 1]])
+    poses = np.stack([synthetic.pose_spherical(a, -30.0, 4.0) for a in (0.0, 77.0, -130.0)], 0).astype(np.float32)
+    images = rs.uniform(0, 1, (n_img, H, W, 3)).astype(np.float32)
+    i_train = [0, 2]
+    rays = np.stack([ref_rays.get_rays_np(H, W, K, p) for p in poses[:, :3, :4]], 0)
+    rays_rgb = np.concatenate([rays, images[:, None]], 1)
+    rays_rgb = np.transpose(rays_rgb, [0, 2, 3, 1, 4])
+    rays_rgb = np.stack([rays_rgb[i] for i in i_train], 0)
+    rays_rgb = np.reshape(rays_rgb, [-1, 3, 3]).astype(np.float32)
+    f.update(gb_K=K, gb_HW=np.array([H, W]), gb_poses=poses, gb_images=images, gb_i_train=np.array(i_train), gb_rays_rgb=rays_rgb)
+    # epoch cursor: (i_batch, epoch) trace of utils.GetterRayBatchIdx for 10 rows, batch 4, 7 calls
+    getter = ref_utils.GetterRayBatchIdx(torch.arange(30, dtype=torch.float32).reshape(10, 3))
+    trace = []
+    for _ in range(7):
+        i_batch, rr, epoch = getter(4)
+        trace.append([i_batch, epoch, int(torch.sort(rr[:, 0]).values.equal(torch.arange(0, 30, 3, dtype=torch.float32)))])
+    f["cursor_trace"] = np.array(trace)
+    save("F10_callers", **f)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_grad_enabled(False)
     R = load_reference()
+    if "--f10" in sys.argv:                                     # only the callers fixture (F1-F9 untouched)
+        f10_callers()
+        return
     rs = np.random.RandomState(1234)
 
     # ---- F1 ray generation --------------------------------------------------------------------
@@ -287,6 +339,7 @@ def main():
                    f"{tag}_rgb_c": rc, f"{tag}_disp_c": dc, f"{tag}_rgb_f": rf, f"{tag}_disp_f": df_,
                    f"{tag}_near": o9.near, f"{tag}_far": o9.far})
     save("F9_batchify", **f9)
+    f10_callers()
     print("done")
 
 

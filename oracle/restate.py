@@ -347,3 +347,37 @@ def counter_uniform(seed: int, stream: int, ray0: int, n_rays: int, n_samples: i
 def mse2psnr(mse: float) -> float:
     """utils.py:10-12."""
     return -10.0 * math.log(max(mse, 1e-30)) / math.log(10.0)
+
+
+# --------------------------------------------------------------------------------------------
+# callers either side of the path (SURVEY.md section 8(f), ranks 2-4): metrics, 8-bit frames, global batch
+# --------------------------------------------------------------------------------------------
+def img2mse(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    return torch.mean((x - y) ** 2)                               # utils.py:18
+
+
+def to8b(x: np.ndarray) -> np.ndarray:
+    return (255 * np.clip(x, 0, 1)).astype(np.uint8)              # utils.py:15
+
+
+def disp8(disp: np.ndarray) -> np.ndarray:
+    return to8b(disp / np.nanmax(disp))                           # test.py:56
+
+
+def rays_rgb_global_batch(H: int, W: int, K, poses: np.ndarray, images: np.ndarray, i_train) -> np.ndarray:
+    """main.py:92-101: [len(i_train)*H*W, 3, 3] float32 = (origin, direction, pixel) per ray, unshuffled."""
+    rays = np.stack([np.stack(get_rays_np(H, W, K, p), 0) for p in poses[:, :3, :4]], 0)          # [N, ro+rd, H, W, 3]
+    rays_rgb = np.concatenate([rays, images[:, None]], 1)                                          # [N, 3, H, W, 3]
+    rays_rgb = np.transpose(rays_rgb, [0, 2, 3, 1, 4])
+    rays_rgb = np.stack([rays_rgb[i] for i in i_train], 0)
+    return np.reshape(rays_rgb, [-1, 3, 3]).astype(np.float32)
+
+
+def pose_spherical(theta: float, phi: float, radius: float) -> torch.Tensor:
+    """dataset/render_pose.py:6-34."""
+    trans_t = torch.Tensor(np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, radius], [0, 0, 0, 1]])).float()
+    ph, th = phi / 180. * np.pi, theta / 180. * np.pi
+    rot_phi = torch.Tensor(np.array([[1, 0, 0, 0], [0, np.cos(ph), -np.sin(ph), 0], [0, np.sin(ph), np.cos(ph), 0], [0, 0, 0, 1]])).float()
+    rot_theta = torch.Tensor(np.array([[np.cos(th), 0, -np.sin(th), 0], [0, 1, 0, 0], [np.sin(th), 0, np.cos(th), 0], [0, 0, 0, 1]])).float()
+    c2w = rot_theta @ (rot_phi @ trans_t)
+    return torch.Tensor(np.array([[-1, 0, 0, 0], [0, 0, 1, 0], [0, 1, 0, 0], [0, 0, 0, 1]])) @ c2w

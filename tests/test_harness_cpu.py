@@ -1,0 +1,68 @@
+"""CPU-side checks of the harness module: camera path against the reference's own
+output (fixture F10), the PNG encoder, checkpoint ingest in the reference's format.  No GPU compute."""
+import os
+import struct
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from nerf_pytorch_paeng_amd import harness, synthetic
+from nerf_pytorch_paeng_amd._lib import MiNerfError
+from nerf_pytorch_paeng_amd.model import NeRF
+
+
+def test_render_pose_matches_reference(golden):
+    g = golden("F10_callers")
+    np.testing.assert_array_equal(harness.get_render_pose(n_angle=8, single_angle=-1, phi=-30.0, nf=4.0).numpy(), g["poses8"])
+    np.testing.assert_array_equal(harness.get_render_pose(n_angle=1, single_angle=120, phi=-20.0, nf=3.5).numpy(), g["pose_single"])
+    np.testing.assert_array_equal(harness.pose_spherical(33.0, -41.0, 4.0).numpy(), g["pose_sph"])
+
+
+def _decode_png(path):
+    b = open(path, "rb").read()
+    assert b[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, chunks = 8, {}
+    while pos < len(b):
+        n, tag = struct.unpack(">I4s", b[pos:pos + 8])
+        data = b[pos + 8:pos + 8 + n]
+        assert struct.unpack(">I", b[pos + 8 + n:pos + 12 + n])[0] == zlib.crc32(tag + data) & 0xFFFFFFFF
+        chunks.setdefault(tag, b"")
+        chunks[tag] += data
+        pos += 12 + n
+    w, h, depth, color = struct.unpack(">IIBB", chunks[b"IHDR"][:10])
+    ch = {0: 1, 2: 3}[color]
+    raw = np.frombuffer(zlib.decompress(chunks[b"IDAT"]), np.uint8).reshape(h, 1 + w * ch)
+    assert depth == 8 and (raw[:, 0] == 0).all()
+    return raw[:, 1:].reshape(h, w, ch)
+
+
+@pytest.mark.parametrize("shape", [(5, 7, 3), (4, 6), (3, 3, 1)])
+def test_png_roundtrip(tmp_path, shape):
+    img = np.random.RandomState(0).randint(0, 256, shape).astype(np.uint8)
+    p = str(tmp_path / "a.png")
+    harness.write_png(p, img)
+    np.testing.assert_array_equal(_decode_png(p).reshape(img.shape), img)
+    with pytest.raises(MiNerfError):
+        harness.write_png(p, img.astype(np.float32))
+
+
+def test_checkpoint_ingest_reference_format(tmp_path):
+    """train.py:105-114 saves {'idx', 'model_state_dict', 'optimizer_state_dict'}; test.py:20-21 loads it."""
+    src = NeRF(4, 128, 63, 27)
+    src.load_state_dict({k: torch.as_tensor(v) for k, v in synthetic.make_state_dict(9, 4, 128).items()})
+    opt = torch.optim.Adam(src.parameters(), lr=5e-4)
+    exp = "lego_exp"
+    os.makedirs(tmp_path / exp)
+    path = harness._ckpt_path(str(tmp_path), exp, 1000)
+    torch.save({"idx": 1000, "model_state_dict": src.state_dict(), "optimizer_state_dict": opt.state_dict()}, path)
+    assert path.endswith(os.path.join(exp, "lego_exp_1000.pth.tar"))
+    dst = NeRF(4, 128, 63, 27)
+    ck = harness.load_checkpoint(path, dst)
+    assert ck["idx"] == 1000
+    for (k, a), (_, b) in zip(src.state_dict().items(), dst.state_dict().items()):
+        assert torch.equal(a, b), k
+    torch.save({"idx": 1}, path)
+    with pytest.raises(MiNerfError):
+        harness.load_checkpoint(path)
