@@ -222,6 +222,34 @@ def main():
         del model, optim
         torch.cuda.empty_cache()
 
+    # ---- global-batch staging: rays for 100 800x800 training images + epoch shuffle, on the device ----
+    staging = None
+    if rank == 0 and not args.bf16 and not fern and args.train_steps > 0:
+        from nerf_pytorch_paeng_amd import harness
+        n_img = 100
+        imgs = torch.rand(n_img, H, W, 3, device=dev)
+        poses_tr = torch.from_numpy(np.stack([synthetic.pose_spherical(3.6 * i - 180.0, -30.0, 4.0) for i in range(n_img)], 0)).float().to(dev)
+        harness.global_batch(imgs[:2], K, poses_tr[:2], [0, 1], (H, W), dev)                    # warm-up
+        torch.cuda.synchronize(dev)
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        p34 = poses_tr[:, :3, :4].contiguous()
+        perm = torch.randperm(n_img * H * W, device=dev)          # torch's generator: plumbing, not timed
+        e0.record()
+        rr = ops.rays_rgb(W, H, K, p34, imgs)
+        e1.record()
+        rr2 = ops.permute_rows(rr, perm)
+        e2.record()
+        torch.cuda.synchronize(dev)
+        n_rays_gb = n_img * H * W
+        b_gen = n_rays_gb * (12 + 36)                     # read the pixel, write (o, d, rgb)
+        b_perm = n_rays_gb * (36 + 36 + 8)                # gather + write + the permutation itself
+        staging = {"what": f"main.py:92-102 on the device: rays_rgb for {n_img} {H}x{W} images ({n_rays_gb * 36 / 1e9:.2f} GB) + row shuffle",
+                   "rays_rgb_ms": round(e0.elapsed_time(e1), 3), "rays_rgb_GBps": round(b_gen / e0.elapsed_time(e1) / 1e6, 1),
+                   "shuffle_ms": round(e1.elapsed_time(e2), 3), "shuffle_GBps": round(b_perm / e1.elapsed_time(e2) / 1e6, 1),
+                   "hbm_peak_GBps": 8000}
+        del imgs, rr, rr2
+        torch.cuda.empty_cache()
+
     # ---- CPU baseline: the oracle (a port: the reference cannot leave the build container) -------------------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -272,6 +300,8 @@ def main():
         }
         if train is not None:
             line["train"] = train
+        if staging is not None:
+            line["staging"] = staging
         if cpu is not None:
             line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)

@@ -105,22 +105,37 @@ __global__ __launch_bounds__(256) void to8b_kernel(const float* __restrict__ x, 
 // poses [n_img][12] row-major 3x4; images [n_img][H*W][3]; k4 = fx, fy, cx, cy.
 __global__ __launch_bounds__(256) void rays_rgb_kernel(int W, int H, float fx, float fy, float cx, float cy, const float* __restrict__ poses,
                                                         const float* __restrict__ images, long long n_img, float* __restrict__ out) {
+    // a block owns 256 consecutive rays: each thread builds one 9-float row in LDS, then the block streams the 2304 floats
+    // out as consecutive 16-byte stores (a thread writing its own 36-byte row touches 9 cache lines per wave instruction)
+    __shared__ __attribute__((aligned(16))) float tile[256 * 9];
     const long long hw = (long long)H * W;
     const long long total = n_img * hw;
-    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-        const long long img = idx / hw;
-        const long long pix = idx - img * hw;
-        const int py = (int)(pix / W), px = (int)(pix - (long long)py * W);
-        const float* c = poses + img * 12;
-        const float dx = ((float)px - cx) / fx, dy = -((float)py - cy) / fy, dz = -1.0f;     // rays.py:10-11
-        float* o = out + idx * 9;
-        o[0] = c[3]; o[1] = c[7]; o[2] = c[11];                                               // rays.py:16
-        // np.sum(dirs[..., None, :] * c2w[:3,:3], -1): left-to-right fp32 sum of three products (rays.py:14)
-        o[3] = (dx * c[0] + dy * c[1]) + dz * c[2];
-        o[4] = (dx * c[4] + dy * c[5]) + dz * c[6];
-        o[5] = (dx * c[8] + dy * c[9]) + dz * c[10];
-        const float* p = images + idx * 3;
-        o[6] = p[0]; o[7] = p[1]; o[8] = p[2];
+    const long long nblk = (total + 255) / 256;
+    for (long long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const long long idx = blk * 256 + threadIdx.x;
+        if (idx < total) {
+            const long long img = idx / hw;
+            const long long pix = idx - img * hw;
+            const int py = (int)(pix / W), px = (int)(pix - (long long)py * W);
+            const float* c = poses + img * 12;
+            const float dx = ((float)px - cx) / fx, dy = -((float)py - cy) / fy, dz = -1.0f;     // rays.py:10-11
+            float* o = tile + threadIdx.x * 9;
+            o[0] = c[3]; o[1] = c[7]; o[2] = c[11];                                               // rays.py:16
+            // np.sum(dirs[..., None, :] * c2w[:3,:3], -1): left-to-right fp32 sum of three products (rays.py:14)
+            o[3] = (dx * c[0] + dy * c[1]) + dz * c[2];
+            o[4] = (dx * c[4] + dy * c[5]) + dz * c[6];
+            o[5] = (dx * c[8] + dy * c[9]) + dz * c[10];
+            const float* p = images + idx * 3;
+            o[6] = p[0]; o[7] = p[1]; o[8] = p[2];
+        }
+        __syncthreads();
+        const long long base = blk * 256 * 9;                      // multiple of 4 floats: 16-byte aligned
+        const long long lim = (total * 9 - base < 2304) ? total * 9 - base : 2304;
+        for (int q = threadIdx.x * 4; q < lim; q += 1024) {
+            if (q + 4 <= lim) *(f32x4*)(out + base + q) = *(const f32x4*)(tile + q);
+            else for (int e = q; e < lim; ++e) out[base + e] = tile[e];
+        }
+        __syncthreads();
     }
 }
 
