@@ -215,3 +215,44 @@ def test_drop_in_training_loop_runs_and_repacks():
     b = NP.batchify_rays_and_render_by_chunk(o, d, model, posenc, H, Wd, K, opts, t_rand=t_rand, u=u)
     assert b[0].requires_grad and not a[0].requires_grad
     assert torch.equal(a[0], b[0].detach()) and torch.equal(a[2], b[2].detach())
+
+
+@pytest.mark.parametrize("Sc,Nf", [(40, 0), (24, 17)])
+def test_train_step_variants_small_net(Sc, Nf):
+    """4x128 network, sample counts that are not multiples of the 32-point tile, coarse-only training (N_samples_f = 0,
+    nerf_process.py:249-252 returns None for the fine outputs)."""
+    from nerf_pytorch_paeng_amd import nerf_process as NP, train_path
+    sd, model, posenc, opts, o, d, t_rand, u, target, cfg = _train_setup(D=4, W=128, n=50, Sc=Sc, Nf=max(Nf, 1), seed=5)
+    opts.N_samples_f = Nf
+    cfg = R.PathConfig(near=2.0, far=6.0, N_samples_c=Sc, N_samples_f=Nf, perturb=1.0, netDepth=4, netWidth=128)
+    u = u[:, :Nf] if Nf else None
+    rays = torch.cat([o, d], -1).contiguous()
+    z_c = R.stratified_z(rays.shape[0], cfg.near, cfg.far, Sc, t_rand)
+    z_f = None
+    if Nf:
+        with torch.no_grad():
+            z_f = NP.render_rays(rays, model, posenc, opts, t_rand=t_rand, u=u, return_intermediates=True)["_z_f"]
+    psd = {k: torch.as_tensor(v).clone().float().requires_grad_(True) for k, v in sd.items()}
+    ref = R.render_rays(rays.cpu(), psd, cfg, t_rand, u, z_fine_override=None if z_f is None else z_f.cpu())
+    loss_ref = torch.mean((ref["rgb_c"] - target) ** 2)
+    if Nf:
+        loss_ref = loss_ref + torch.mean((ref["rgb_f"] - target) ** 2)
+    loss_ref.backward()
+    out = train_path.render_train(rays, model, opts, t_rand=t_rand, u=u, z_override=(z_c.to(DEV), z_f))
+    tgt = target.to(DEV)
+    loss = torch.mean((out["rgb_c"] - tgt) ** 2)
+    if Nf:
+        loss = loss + torch.mean((out["rgb_f"] - tgt) ** 2)
+    else:
+        assert "rgb_f" not in out
+    loss.backward()
+    assert abs(loss.item() - loss_ref.item()) < 1e-5
+    for k, p in model.named_parameters():
+        if not Nf and k.startswith("model_fine."):
+            assert p.grad is None and psd[k].grad is None            # the fine network takes no part in a coarse-only step
+            continue
+        assert rel_err(p.grad, psd[k].grad) < 1e-4, k
+    # drop-in surface: 4-tuple with None for the fine outputs when N_samples_f == 0
+    K, H, Wd = synthetic.lego_camera()
+    res = NP.batchify_rays_and_render_by_chunk(o, d, model, posenc, H, Wd, K, opts, t_rand=t_rand, u=u)
+    assert res[0].requires_grad and (res[2] is None) == (Nf == 0)
