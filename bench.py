@@ -306,6 +306,7 @@ def main():
             line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)
     if world > 1:
+        barrier()                      # rank 0 may still be printing / staging: tear the group down together
         dist.destroy_process_group()
 
 
