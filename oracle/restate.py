@@ -167,6 +167,7 @@ def fine_z(z_coarse: torch.Tensor, weights_coarse: torch.Tensor, n_fine: int, de
     """Merged, sorted fine sample depths (nerf_process.py:63-67).  Returns (z_fine, z_samples)."""
     mids = 0.5 * (z_coarse[..., 1:] + z_coarse[..., :-1])         # :63
     z_new = sample_pdf(mids, weights_coarse[..., 1:-1], n_fine, det, u)       # :64-65
+    z_new = z_new.detach()                                        # :66 -- the fine loss never reaches the coarse network
     z_all, _ = torch.sort(torch.cat([z_coarse, z_new], -1), -1)   # :67
     return z_all, z_new
 
