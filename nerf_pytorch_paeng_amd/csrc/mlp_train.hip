@@ -273,63 +273,168 @@ void wgrad_big_kernel(const WgradArgs a) {
     }
 }
 
-// 64 x 64 block per workgroup (2x2 waves, one tile each) for the narrow operands: encoded inputs (63 / 27 columns,
-// row pitch 90), the 3-wide colour and 1-wide density gradients.  HBM bound; many small workgroups per CU.
-__global__ __launch_bounds__(256)
-void wgrad_small_kernel(const WgradArgs a) {
-    constexpr int U = 8;
+// Products with one NARROW operand: the encoded inputs gamma(x) (63 columns) and gamma(d) (27), row pitch 90, and the
+// 3-wide colour / 1-wide density gradients in d_raw (row pitch 4).  The other operand is a W- or W/2-wide row-major tensor.
+// One WAVE owns all of the output, wide (128 WQ columns, fetched like wgrad_big_kernel: lane i takes columns 4i..4i+3 of
+// each 128-column group with one 16-byte load) x narrow (32 NN columns, one 4-byte load each), over its own slice of the
+// points; 4 WQ NN MFMAs per point pair against 16 WQ + 4 NN bytes per lane.  Output rows = wide index, columns = narrow
+// index; the reduction transposes when the gradient operand is the narrow one.
+struct NarrowArgs {
+    const float* wide; int ldw; int Mw;      // [P, ldw], columns [0, Mw), Mw <= 128 WQ, 16-byte aligned, ldw % 4 == 0
+    const float* nar;  int ldn; int Nn;      // [P, ldn], columns [0, Nn), Nn <= 32 NN
+    long long P;
+    int pps;                                 // points per slice (one slice per wave)
+    float* partial;                          // [slices][128 WQ][32 NN]
+    float* wsum;                             // [slices][128 WQ]  column sums of the wide operand, or NULL
+    float* nsum;                             // [slices][32 NN]   column sums of the narrow operand, or NULL
+};
+
+template <int WQ, int NN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
+void wgrad_narrow_kernel(const NarrowArgs a) {
+    constexpr int U = (WQ * NN == 4) ? 4 : 6;      // k-steps per pipeline stage: 3 register sets next to 64 WQ NN accumulators
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 31, kh = lane >> 5;
-    const int m0 = blockIdx.y * 64 + (wave >> 1) * 32;
-    const int n0 = blockIdx.z * 64 + (wave & 1) * 32;
-    const long long pb = (long long)blockIdx.x * a.pps;
-    const long long pe = (pb + a.pps < a.P) ? pb + a.pps : a.P;
-    const bool aok = m0 + i < a.M, bok = n0 + i < a.N;
-    const float* abase = a.dlt + m0 + i;
-    const float* bbase = a.x + n0 + i;
-    const float* zp = g_zero16;
-    f32x16 acc;
+    // one point slice per wave; the four waves of a workgroup add their results through LDS (fixed order) before the
+    // workgroup writes ONE partial, so the reduction kernel sees a quarter of the slices
+    const long long slice = (long long)blockIdx.x * 4 + wave;
+    const long long pb = slice * a.pps;
+    const bool active = pb < a.P;            // tail waves past the last slice multiply zeros and still join the barriers
+    const long long pe = !active ? pb : ((pb + a.pps < a.P) ? pb + a.pps : a.P);
+
+    bool wok[WQ], nok[NN];
+    const float* pw[WQ];
+    long long sw[WQ];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    float bsum = 0.0f;
-    for (long long p = pb; p < pe; p += 2 * U) {
-        float ca[U], cb[U];
+    for (int q = 0; q < WQ; ++q) {
+        wok[q] = active && 128 * q + 4 * i < a.Mw;
+        pw[q] = wok[q] ? a.wide + (pb + kh) * a.ldw + 128 * q + 4 * i : g_zero16;
+        sw[q] = wok[q] ? (long long)a.ldw * 2 : 0;
+    }
+    const float* pn[NN];
+#pragma unroll
+    for (int q = 0; q < NN; ++q) { nok[q] = active && 32 * q + i < a.Nn; pn[q] = a.nar + 32 * q + i; }
+
+    f32x16 acc[4 * WQ][NN];
+#pragma unroll
+    for (int tm = 0; tm < 4 * WQ; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < NN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.0f;
+    f32x4 wsum[WQ];
+    float nsum[NN];
+#pragma unroll
+    for (int q = 0; q < WQ; ++q) wsum[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < NN; ++q) nsum[q] = 0.0f;
+
+    // three register sets rotated by name, loads behind each k-step's MFMAs, rows past the slice end zeroed in both
+    // operands: see wgrad_big_kernel.  The wide operand may be read up to five groups past the slice end (padding from
+    // train_layout()); the narrow operand can be a caller tensor (d_raw), so its address is clamped to the zero buffer.
+    struct Set { f32x4 w[U][WQ]; float n[U][NN]; };
+    Set c, nx, f;
+    long long row = pb + kh;                 // next row to request for this lane half
+    auto request = [&](Set& S, int u) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < WQ; ++q) { S.w[u][q] = *(const f32x4*)pw[q]; pw[q] += sw[q]; }
+        const bool in = row < a.P;
+#pragma unroll
+        for (int q = 0; q < NN; ++q) {
+            const float* p = (in && nok[q]) ? pn[q] + row * a.ldn : g_zero16;
+            S.n[u][q] = *p;
+        }
+        row += 2;
+    };
+#pragma unroll
+    for (int u = 0; u < U; ++u) request(c, u);
+#pragma unroll
+    for (int u = 0; u < U; ++u) request(nx, u);
+    int rows_left = (int)(pe - pb) - kh;
+    auto step = [&](Set& A, Set& F) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const long long row = p + 2 * u + kh;
-            const bool ok = row < pe;
-            const float* qa = (ok && aok) ? abase + row * a.ldd : zp;
-            const float* qb = (ok && bok) ? bbase + row * a.ldx : zp;
-            ca[u] = *qa;
-            cb[u] = *qb;
+            const bool ok = 2 * u < rows_left;
+#pragma unroll
+            for (int q = 0; q < WQ; ++q) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) A.w[u][q][e] = ok ? A.w[u][q][e] : 0.0f;
+                wsum[q] += A.w[u][q];
+            }
+#pragma unroll
+            for (int q = 0; q < NN; ++q) { A.n[u][q] = ok ? A.n[u][q] : 0.0f; nsum[q] += A.n[u][q]; }
+#pragma unroll
+            for (int tm = 0; tm < 4 * WQ; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < NN; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(A.w[u][tm >> 2][tm & 3], A.n[u][tn], acc[tm][tn], 0, 0, 0);
+            request(F, u);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        rows_left -= 2 * U;
+    };
+    const long long n_groups = (pe - pb + 2 * U - 1) / (2 * U);
+    for (long long g = 0; g < n_groups; g += 3) {
+        step(c, f);
+        step(nx, c);
+        step(f, nx);
+    }
+    // D[i'][j]: i' = (r&3) + 8*(r>>2) + 4*kh <-> wide column 128*(tm>>2) + 4*i' + (tm&3);  j = lane & 31 <-> narrow column 32*tn + j
+    constexpr int Wp = 128 * WQ, Np = 32 * NN;
+    __shared__ float red[3][16][64];
+    float* out = a.partial + (size_t)blockIdx.x * Wp * Np;
+#pragma unroll
+    for (int tm = 0; tm < 4 * WQ; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < NN; ++tn) {
+            if (wave > 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[wave - 1][r][lane] = acc[tm][tn][r];
+            }
+            __syncthreads();
+            if (wave == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = ((acc[tm][tn][r] + red[0][r][lane]) + red[1][r][lane]) + red[2][r][lane];
+                    const int w = 128 * (tm >> 2) + 4 * ((r & 3) + 8 * (r >> 2) + 4 * kh) + (tm & 3);
+                    out[(size_t)w * Np + 32 * tn + i] = v;
+                }
+            }
+            __syncthreads();
+        }
+    // column sums (bias gradients): even + odd points of every k-step, then the four waves
+    float* sums = &red[0][0][0];             // [4 waves][Wp + Np] floats fit easily
+#pragma unroll
+    for (int q = 0; q < WQ; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float v = wsum[q][e] + __shfl_xor(wsum[q][e], 32, 64);
+            if (kh == 0) sums[wave * (Wp + Np) + 128 * q + 4 * i + e] = v;
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            bsum += ca[u];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[u], cb[u], acc, 0, 0, 0);
-        }
+    for (int q = 0; q < NN; ++q) {
+        const float v = nsum[q] + __shfl_xor(nsum[q], 32, 64);
+        if (kh == 0) sums[wave * (Wp + Np) + Wp + 32 * q + i] = v;
     }
-    float* out = a.partial + (size_t)blockIdx.x * a.Mp * a.Np;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        out[(size_t)m * a.Np + n0 + i] = acc[r];
-    }
-    if (a.bpartial && blockIdx.z == 0 && (wave & 1) == 0) {
-        const float s = bsum + __shfl_xor(bsum, 32, 64);
-        if (kh == 0) a.bpartial[(size_t)blockIdx.x * a.Mp + m0 + i] = s;
+    __syncthreads();
+    for (int c = threadIdx.x; c < Wp + Np; c += 256) {
+        const float v = ((sums[c] + sums[(Wp + Np) + c]) + sums[2 * (Wp + Np) + c]) + sums[3 * (Wp + Np) + c];
+        if (c < Wp) { if (a.wsum) a.wsum[(size_t)blockIdx.x * Wp + c] = v; }
+        else if (a.nsum) a.nsum[(size_t)blockIdx.x * Np + (c - Wp)] = v;
     }
 }
 
 // out[m*ldo + n] = sum_s partial[s][m][n]  (m < M, n < N);  bias[m] = sum_s bpartial[s][m]
+// transposed: the partials are stored [n][m] (the gradient operand was the narrow one), i.e. partial[s][n*Mp + m] with
+// Mp the row pitch of that layout.
 __global__ __launch_bounds__(256) void reduce_partial_kernel(const float* __restrict__ partial, const float* __restrict__ bpartial,
                                                               int slices, int Mp, int Np, int M, int N, float* __restrict__ out, int ldo,
-                                                              float* __restrict__ bias) {
+                                                              float* __restrict__ bias, int bias_pitch, int transposed) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx < M * N) {
         const int m = idx / N, n = idx - m * N;
-        const float* p = partial + (size_t)m * Np + n;
+        const float* p = partial + (transposed ? (size_t)n * Np + m : (size_t)m * Np + n);
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
         int s = 0;
         for (; s + 4 <= slices; s += 4) {
@@ -341,7 +446,7 @@ __global__ __launch_bounds__(256) void reduce_partial_kernel(const float* __rest
     } else if (bias && idx < M * N + M) {
         const int m = idx - M * N;
         float s0 = 0.f;
-        for (int s = 0; s < slices; ++s) s0 += bpartial[(size_t)s * Mp + m];
+        for (int s = 0; s < slices; ++s) s0 += bpartial[(size_t)s * bias_pitch + m];
         bias[m] = s0;
     }
 }
@@ -403,34 +508,66 @@ int train_layout(const mi_nerf_net* net, int64_t n_rays, int S, mi_nerf_train_la
 // one dW (+ optional bias) = delta^T x input, slice partials reduced into `out`
 static int run_wgrad(const float* dlt, int ldd, int M, const float* x, int ldx, int N, long long P, float* out, int ldo, float* bias,
                      float* partial, hipStream_t st) {
-    WgradArgs a{};
-    a.dlt = dlt; a.ldd = ldd; a.M = M; a.x = x; a.ldx = ldx; a.N = N; a.P = P;
-    const bool big = (M > 64 && N > 64);
-    if (big)
+    if (M > 64 && N > 64) {                  // W- or W/2-wide on both sides: 256 x 256 block per workgroup
         MN_CHECK_ARG(M % 4 == 0 && N % 4 == 0 && ldd % 4 == 0 && ldx % 4 == 0 && ((uintptr_t)dlt & 15) == 0 && ((uintptr_t)x & 15) == 0,
                      "internal: wgrad operands must be 16-byte aligned with pitches of 4 floats");
-    const int bm = big ? 256 : 64, bn = big ? 256 : 64;
-    const int by = (M + bm - 1) / bm, bz = (N + bn - 1) / bn;
-    a.Mp = by * bm; a.Np = bz * bn;
-    // big: one workgroup per CU owns all registers; small: ~4 workgroups per CU hide the HBM latency by occupancy
-    int slices = (big ? num_cus_t() : 4 * num_cus_t()) / (by * bz);
-    const size_t per_slice = (size_t)a.Mp * a.Np + a.Mp;
-    if ((size_t)slices * per_slice > WGRAD_PARTIAL_FLOATS) slices = (int)(WGRAD_PARTIAL_FLOATS / per_slice);
-    if (slices < 1) slices = 1;
-    long long pps = (P + slices - 1) / slices;
-    pps = (pps + 11) / 12 * 12;          // whole load groups (2 x U points) in every slice but the last
-    slices = (int)((P + pps - 1) / pps);
+        WgradArgs a{};
+        a.dlt = dlt; a.ldd = ldd; a.M = M; a.x = x; a.ldx = ldx; a.N = N; a.P = P;
+        const int by = (M + 255) / 256, bz = (N + 255) / 256;
+        a.Mp = by * 256; a.Np = bz * 256;
+        int slices = num_cus_t() / (by * bz);              // one workgroup per CU owns all registers
+        const size_t per_slice = (size_t)a.Mp * a.Np + a.Mp;
+        if ((size_t)slices * per_slice > WGRAD_PARTIAL_FLOATS) slices = (int)(WGRAD_PARTIAL_FLOATS / per_slice);
+        if (slices < 1) slices = 1;
+        long long pps = (P + slices - 1) / slices;
+        pps = (pps + 11) / 12 * 12;                        // whole load groups (2 x U points) in every slice but the last
+        slices = (int)((P + pps - 1) / pps);
+        MN_CHECK_ARG((size_t)slices * per_slice <= WGRAD_PARTIAL_FLOATS, "internal: wgrad partial buffer too small");
+        a.pps = (int)pps;
+        a.partial = partial;
+        a.bpartial = bias ? partial + (size_t)slices * a.Mp * a.Np : nullptr;
+        hipLaunchKernelGGL(wgrad_big_kernel, dim3(slices, by, bz), dim3(256), 0, st, a);
+        MN_LAUNCH_CHECK("wgrad_big_kernel");
+        const int total = M * N + (bias ? M : 0);
+        hipLaunchKernelGGL(reduce_partial_kernel, dim3((total + 255) / 256), dim3(256), 0, st, (const float*)partial, (const float*)a.bpartial,
+                           slices, a.Mp, a.Np, M, N, out, ldo, bias, a.Mp, 0);
+        MN_LAUNCH_CHECK("reduce_partial_kernel");
+        return MI_NERF_OK;
+    }
+    // one narrow side: the wide operand is whichever has more columns; the partials come out [wide][narrow]
+    const bool delta_is_wide = M >= N;
+    NarrowArgs a{};
+    a.wide = delta_is_wide ? dlt : x; a.ldw = delta_is_wide ? ldd : ldx; a.Mw = delta_is_wide ? M : N;
+    a.nar = delta_is_wide ? x : dlt;  a.ldn = delta_is_wide ? ldx : ldd; a.Nn = delta_is_wide ? N : M;
+    a.P = P;
+    MN_CHECK_ARG(a.Mw <= 256 && a.Nn <= 64 && a.Mw % 4 == 0 && a.ldw % 4 == 0 && ((uintptr_t)a.wide & 15) == 0,
+                 "internal: unsupported narrow wgrad shape %d x %d", M, N);
+    const int WQ = a.Mw > 128 ? 2 : 1, NN = a.Nn > 32 ? 2 : 1;
+    const int Wp = 128 * WQ, Np = 32 * NN;
+    const size_t per_slice = (size_t)Wp * Np + Wp + Np;
+    long long wslices = 4LL * num_cus_t();                 // one point slice per wave, one partial per workgroup
+    long long pps = (P + wslices - 1) / wslices;
+    pps = (pps + 23) / 24 * 24;                          // whole load groups for U = 4 and U = 6
+    wslices = (P + pps - 1) / pps;
+    const long long slices = (wslices + 3) / 4;
     MN_CHECK_ARG((size_t)slices * per_slice <= WGRAD_PARTIAL_FLOATS, "internal: wgrad partial buffer too small");
     a.pps = (int)pps;
     a.partial = partial;
-    a.bpartial = bias ? partial + (size_t)slices * a.Mp * a.Np : nullptr;
-    const dim3 grid(slices, by, bz);
-    if (big) hipLaunchKernelGGL(wgrad_big_kernel, grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(wgrad_small_kernel, grid, dim3(256), 0, st, a);
-    MN_LAUNCH_CHECK("wgrad_kernel");
+    float* wsum = partial + (size_t)slices * Wp * Np;
+    float* nsum = wsum + (size_t)slices * Wp;
+    a.wsum = (bias && delta_is_wide) ? wsum : nullptr;
+    a.nsum = (bias && !delta_is_wide) ? nsum : nullptr;
+    const dim3 grid((unsigned)slices);
+    if (WQ == 2 && NN == 2) hipLaunchKernelGGL((wgrad_narrow_kernel<2, 2>), grid, dim3(256), 0, st, a);
+    else if (WQ == 2) hipLaunchKernelGGL((wgrad_narrow_kernel<2, 1>), grid, dim3(256), 0, st, a);
+    else if (NN == 2) hipLaunchKernelGGL((wgrad_narrow_kernel<1, 2>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((wgrad_narrow_kernel<1, 1>), grid, dim3(256), 0, st, a);
+    MN_LAUNCH_CHECK("wgrad_narrow_kernel");
     const int total = M * N + (bias ? M : 0);
-    hipLaunchKernelGGL(reduce_partial_kernel, dim3((total + 255) / 256), dim3(256), 0, st, (const float*)partial, (const float*)a.bpartial,
-                       slices, a.Mp, a.Np, M, N, out, ldo, bias);
+    // reduce: rows of the partial are the wide index.  delta wide: out[m][n] = partial[m][n];  delta narrow: out[m][n] = partial[n][m]
+    hipLaunchKernelGGL(reduce_partial_kernel, dim3((total + 255) / 256), dim3(256), 0, st, (const float*)partial,
+                       (const float*)(delta_is_wide ? wsum : nsum), (int)slices, Wp, Np, M, N, out, ldo, bias, delta_is_wide ? Wp : Np,
+                       delta_is_wide ? 0 : 1);
     MN_LAUNCH_CHECK("reduce_partial_kernel");
     return MI_NERF_OK;
 }
