@@ -431,23 +431,35 @@ void wgrad_narrow_kernel(const NarrowArgs a) {
 __global__ __launch_bounds__(256) void reduce_partial_kernel(const float* __restrict__ partial, const float* __restrict__ bpartial,
                                                               int slices, int Mp, int Np, int M, int N, float* __restrict__ out, int ldo,
                                                               float* __restrict__ bias, int bias_pitch, int transposed) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+    // a block sums 64 outputs: 4 groups of 64 threads take every 4th slice (8 loads in flight each), then add up through
+    // LDS in a fixed order -- 4 blocks per CU instead of one thread per output walking all slices alone
+    __shared__ float red[4][64];
+    const int g = threadIdx.x >> 6, o = threadIdx.x & 63;
+    const int idx = blockIdx.x * 64 + o;
+    const int total = M * N + (bias ? M : 0);
+    float acc = 0.0f;
     if (idx < M * N) {
         const int m = idx / N, n = idx - m * N;
         const float* p = partial + (transposed ? (size_t)n * Np + m : (size_t)m * Np + n);
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        int s = 0;
-        for (; s + 4 <= slices; s += 4) {
-            s0 += p[(size_t)(s + 0) * Mp * Np]; s1 += p[(size_t)(s + 1) * Mp * Np];
-            s2 += p[(size_t)(s + 2) * Mp * Np]; s3 += p[(size_t)(s + 3) * Mp * Np];
+        const size_t stride = (size_t)Mp * Np;
+        float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int sl = g;
+        for (; sl + 28 < slices; sl += 32) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s[k] += p[(size_t)(sl + 4 * k) * stride];
         }
-        for (; s < slices; ++s) s0 += p[(size_t)s * Mp * Np];
-        out[(size_t)m * ldo + n] = (s0 + s1) + (s2 + s3);
-    } else if (bias && idx < M * N + M) {
+        for (; sl < slices; sl += 4) s[0] += p[(size_t)sl * stride];
+        acc = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    } else if (idx < total) {
         const int m = idx - M * N;
-        float s0 = 0.f;
-        for (int s = 0; s < slices; ++s) s0 += bpartial[(size_t)s * bias_pitch + m];
-        bias[m] = s0;
+        for (int sl = g; sl < slices; sl += 4) acc += bpartial[(size_t)sl * bias_pitch + m];
+    }
+    red[g][o] = acc;
+    __syncthreads();
+    if (g == 0 && idx < total) {
+        const float v = ((red[0][o] + red[1][o]) + red[2][o]) + red[3][o];
+        if (idx < M * N) { const int m = idx / N, n = idx - m * N; out[(size_t)m * ldo + n] = v; }
+        else bias[idx - M * N] = v;
     }
 }
 
@@ -529,7 +541,7 @@ static int run_wgrad(const float* dlt, int ldd, int M, const float* x, int ldx, 
         hipLaunchKernelGGL(wgrad_big_kernel, dim3(slices, by, bz), dim3(256), 0, st, a);
         MN_LAUNCH_CHECK("wgrad_big_kernel");
         const int total = M * N + (bias ? M : 0);
-        hipLaunchKernelGGL(reduce_partial_kernel, dim3((total + 255) / 256), dim3(256), 0, st, (const float*)partial, (const float*)a.bpartial,
+        hipLaunchKernelGGL(reduce_partial_kernel, dim3((total + 63) / 64), dim3(256), 0, st, (const float*)partial, (const float*)a.bpartial,
                            slices, a.Mp, a.Np, M, N, out, ldo, bias, a.Mp, 0);
         MN_LAUNCH_CHECK("reduce_partial_kernel");
         return MI_NERF_OK;
@@ -565,7 +577,7 @@ static int run_wgrad(const float* dlt, int ldd, int M, const float* x, int ldx, 
     MN_LAUNCH_CHECK("wgrad_narrow_kernel");
     const int total = M * N + (bias ? M : 0);
     // reduce: rows of the partial are the wide index.  delta wide: out[m][n] = partial[m][n];  delta narrow: out[m][n] = partial[n][m]
-    hipLaunchKernelGGL(reduce_partial_kernel, dim3((total + 255) / 256), dim3(256), 0, st, (const float*)partial,
+    hipLaunchKernelGGL(reduce_partial_kernel, dim3((total + 63) / 64), dim3(256), 0, st, (const float*)partial,
                        (const float*)(delta_is_wide ? wsum : nsum), (int)slices, Wp, Np, M, N, out, ldo, bias, delta_is_wide ? Wp : Np,
                        delta_is_wide ? 0 : 1);
     MN_LAUNCH_CHECK("reduce_partial_kernel");
