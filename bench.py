@@ -219,7 +219,15 @@ def main():
                  "frac_of_f32_mfma_roofline": round(N_RAYS / (t_ms * 1e-3) * train_flop_per_ray / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                  "what": "batchify_rays_and_render_by_chunk (grad) + MSE(rgb_c)+MSE(rgb_f) + loss.backward() + Adam.step(), "
                          f"{N_RAYS} rays per GPU, each rank an independent replica (the reference has no data-parallel training)"}
-        del model, optim
+        # roofline leg of the training kernels' GEMM: one 256x256 weight-gradient product over the fine net's 786 432 points
+        dlt = torch.randn(N_RAYS * (SC + NF) + 64, 256, device=dev)
+        xin = torch.randn(N_RAYS * (SC + NF) + 64, 256, device=dev)
+        ops.wgrad_product(dlt, 256, xin, 256, N_RAYS * (SC + NF), iters=2)
+        _, _, wg_ms = ops.wgrad_product(dlt, 256, xin, 256, N_RAYS * (SC + NF), iters=10, timed=True)
+        wg_tf = 2.0 * 256 * 256 * N_RAYS * (SC + NF) / (wg_ms * 1e-3) / 1e12
+        train["wgrad_256x256"] = {"ms": round(wg_ms, 4), "achieved_TFLOPs": round(wg_tf, 1), "frac_of_f32_mfma_peak": round(wg_tf / PEAK_F32_MFMA_TFLOPS, 4),
+                                  "what": "wgrad_big_kernel + reduce_partial_kernel, hipEvents on the launch stream"}
+        del model, optim, dlt, xin
         torch.cuda.empty_cache()
 
     # ---- global-batch staging: rays for 100 800x800 training images + epoch shuffle, on the device ----

@@ -31,6 +31,7 @@ int mlp_rays_fp32_stash(const mi_nerf_net*, const void*, const float*, const flo
 int mlp_backward_fp32(const mi_nerf_net*, const void*, const void*, const float*, const float*, int64_t, int, const float*, const void*, void*,
                       size_t, float*, int, hipStream_t);
 int train_layout(const mi_nerf_net*, int64_t, int, mi_nerf_train_layout*);
+int wgrad_product(const float*, int, int, const float*, int, int, int64_t, float*, int, float*, void*, size_t, hipStream_t);
 int pack_apply(const int32_t*, const float*, size_t, void*, hipStream_t);
 int pack_bwd_fp32(const mi_nerf_net*, const mi_nerf_params*, void*, size_t);
 size_t packed_bytes_bwd(const mi_nerf_net*);
@@ -301,6 +302,30 @@ int mi_nerf_time_mlp_rays(const mi_nerf_net* net, const void* packed, const floa
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     *avg_ms = ms / (float)iters;
+    return rc;
+}
+
+int mi_nerf_wgrad_product(const float* delta, int ldd, int M, const float* x, int ldx, int N, int64_t P, float* out, int ldo, float* bias,
+                          void* scratch, size_t scratch_bytes, int iters, float* avg_ms, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    MN_CHECK_ARG(iters >= 1, "bad iters");
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (avg_ms) {
+        MN_HIP(hipEventCreate(&e0));
+        MN_HIP(hipEventCreate(&e1));
+        MN_HIP(hipEventRecord(e0, st));
+    }
+    int rc = MI_NERF_OK;
+    for (int i = 0; i < iters && rc == MI_NERF_OK; ++i) rc = wgrad_product(delta, ldd, M, x, ldx, N, P, out, ldo, bias, scratch, scratch_bytes, st);
+    if (avg_ms) {
+        MN_HIP(hipEventRecord(e1, st));
+        MN_HIP(hipEventSynchronize(e1));
+        float ms = 0.f;
+        MN_HIP(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        *avg_ms = ms / (float)iters;
+    }
     return rc;
 }
 

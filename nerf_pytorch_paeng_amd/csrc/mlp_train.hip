@@ -197,8 +197,6 @@ void wgrad_big_kernel(const WgradArgs a) {
     const int i = lane & 31, kh = lane >> 5;
     const int m0 = blockIdx.y * 256 + (wave >> 1) * 128;
     const int n0 = blockIdx.z * 256 + (wave & 1) * 128;
-    const long long pb = (long long)blockIdx.x * a.pps;
-    const long long pe = (pb + a.pps < a.P) ? pb + a.pps : a.P;
     const bool aok = m0 + 4 * i < a.M, bok = n0 + 4 * i < a.N;
     const float* abase = a.dlt + m0 + 4 * i;
     const float* bbase = a.x + n0 + 4 * i;
@@ -212,45 +210,47 @@ void wgrad_big_kernel(const WgradArgs a) {
             for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.0f;
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
 
-    // Main loop: whole groups of 2U points, no masking, one running pointer per operand (masked-off lanes walk the zero
-    // buffer with stride 0).  Three-stage software pipeline, and the two loads of a k-step are issued right behind the 16
-    // MFMAs of the same k-step of the CURRENT stage: left to itself hipcc puts all address arithmetic and loads of an
-    // iteration in one block in front of the 96 MFMAs, and the matrix pipe idles ~15% of the time (PMC: 80.7% busy).
-    // The pipeline reads up to four groups past the slice end: rows of the next slice, or (last slice) of the padding
-    // train_layout() leaves behind every operand; those values are zeroed before they are multiplied.
-    const long long stride_a = aok ? (long long)a.ldd * 2 : 0, stride_b = bok ? (long long)a.ldx * 2 : 0;     // floats per k-step
-    const float* pa = aok ? abase + (pb + kh) * a.ldd : g_zero16;
-    const float* pbp = bok ? bbase + (pb + kh) * a.ldx : g_zero16;
+    // The points are dealt to the workgroups in GROUPS of 2U rows, round robin: group g of workgroup s is rows
+    // [(g * slices + s) * 2U, ... + 2U).  At any moment the whole chip streams one window of slices x 2U consecutive rows per
+    // operand (3 MB) instead of 256 separate regions hundreds of MB apart -- contiguous per-workgroup slices lose 10-25 % to
+    // the memory system as P grows (tools/wgrad_probe.py).  Rows at or past P are never fetched: the address is switched to
+    // a zero buffer (a value select after the load would wrap every load in an exec-masked block with its own s_waitcnt).
+    // Three register sets rotated by NAME (loop unrolled by 3; a copy of a just-requested set forces s_waitcnt vmcnt(0)),
+    // and the two loads of a k-step are issued right behind the 16 MFMAs of the same k-step of the current set.
+    const long long slices = gridDim.x;
+    const long long gstride = slices * (2 * U);              // rows between consecutive groups of one workgroup
+    long long req_row = (long long)blockIdx.x * (2 * U) + kh;     // next row this lane half requests
+    int req_u = 0;
     f32x4 ca[U], cb[U], na[U], nb[U], fa[U], fb[U];
+    auto request = [&](f32x4& A, f32x4& B) __attribute__((always_inline)) {
+        const bool in = req_row < a.P;
+        const f32x4* qa = (in && aok) ? (const f32x4*)(abase + req_row * a.ldd) : (const f32x4*)g_zero16;
+        const f32x4* qb = (in && bok) ? (const f32x4*)(bbase + req_row * a.ldx) : (const f32x4*)g_zero16;
+        A = *qa;
+        B = *qb;
+        req_row += 2;
+        if (++req_u == U) { req_u = 0; req_row += gstride - 2 * U; }
+    };
 #pragma unroll
-    for (int u = 0; u < U; ++u) { ca[u] = *(const f32x4*)pa; cb[u] = *(const f32x4*)pbp; pa += stride_a; pbp += stride_b; }
+    for (int u = 0; u < U; ++u) request(ca[u], cb[u]);
 #pragma unroll
-    for (int u = 0; u < U; ++u) { na[u] = *(const f32x4*)pa; nb[u] = *(const f32x4*)pbp; pa += stride_a; pbp += stride_b; }
-    // one group: multiply stage (A, B) while stage (FA, FB) is being requested.  The three register sets rotate by NAME
-    // (loop unrolled by 3), never by copy: a copy of a just-requested set forces s_waitcnt vmcnt(0) at the loop head,
-    // i.e. a prefetch distance of a fraction of one group instead of two.  Rows at or past the slice end are zeroed in
-    // BOTH operands (the other side may hold anything, 0 x NaN = NaN), 8 v_cndmask per 16 MFMAs; that keeps the loop
-    // free of remainder paths (which cost 1.4 KB of scratch per lane when written as branches).
-    int rows_left = (int)(pe - pb) - kh;                  // this lane half's rows: 0, 2, 4, ... (kh = 0) or 1, 3, ... (kh = 1)
+    for (int u = 0; u < U; ++u) request(na[u], nb[u]);
     auto step = [&](f32x4 (&A)[U], f32x4 (&B)[U], f32x4 (&FA)[U], f32x4 (&FB)[U]) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const bool ok = 2 * u < rows_left;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { A[u][e] = ok ? A[u][e] : 0.0f; B[u][e] = ok ? B[u][e] : 0.0f; }
             bsum += A[u];
 #pragma unroll
             for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
                 for (int tn = 0; tn < 4; ++tn)
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[u][tm], B[u][tn], acc[tm][tn], 0, 0, 0);
-            FA[u] = *(const f32x4*)pa; FB[u] = *(const f32x4*)pbp; pa += stride_a; pbp += stride_b;
+            request(FA[u], FB[u]);
             __builtin_amdgcn_sched_barrier(0);
         }
-        rows_left -= 2 * U;
     };
-    const long long n_groups = (pe - pb + 2 * U - 1) / (2 * U);
-    for (long long g = 0; g < n_groups; g += 3) {           // a multiple of 3 groups; surplus groups multiply zeros
+    const long long all_groups = (a.P + 2 * U - 1) / (2 * U);
+    const long long n_groups = (all_groups + slices - 1) / slices;       // per workgroup; surplus groups multiply zeros
+    for (long long g = 0; g < n_groups; g += 3) {
         step(ca, cb, fa, fb);
         step(na, nb, ca, cb);
         step(fa, fb, na, nb);
@@ -487,7 +487,7 @@ static int num_cus_t() {
 }
 
 static inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
-// wgrad_big_kernel's load pipeline runs up to 5 groups x 12 rows x 1 KiB past the end of an operand
+// wgrad_narrow_kernel's load pipeline runs up to 5 groups x 12 rows x 1 KiB past the end of its wide operand
 constexpr size_t WGRAD_OVERRUN_PAD = 128 * 1024;
 
 constexpr size_t WGRAD_PARTIAL_FLOATS = (size_t)256 * 256 * 256 + (size_t)256 * 256;   // 256 slices of a 256x256 block + bias rows
@@ -530,12 +530,11 @@ static int run_wgrad(const float* dlt, int ldd, int M, const float* x, int ldx, 
         int slices = num_cus_t() / (by * bz);              // one workgroup per CU owns all registers
         const size_t per_slice = (size_t)a.Mp * a.Np + a.Mp;
         if ((size_t)slices * per_slice > WGRAD_PARTIAL_FLOATS) slices = (int)(WGRAD_PARTIAL_FLOATS / per_slice);
+        const long long all_groups = (P + 11) / 12;        // groups of 2 x U points, dealt round robin to the workgroups
+        if (slices > all_groups) slices = (int)all_groups;
         if (slices < 1) slices = 1;
-        long long pps = (P + slices - 1) / slices;
-        pps = (pps + 11) / 12 * 12;                        // whole load groups (2 x U points) in every slice but the last
-        slices = (int)((P + pps - 1) / pps);
         MN_CHECK_ARG((size_t)slices * per_slice <= WGRAD_PARTIAL_FLOATS, "internal: wgrad partial buffer too small");
-        a.pps = (int)pps;
+        a.pps = 0;
         a.partial = partial;
         a.bpartial = bias ? partial + (size_t)slices * a.Mp * a.Np : nullptr;
         hipLaunchKernelGGL(wgrad_big_kernel, dim3(slices, by, bz), dim3(256), 0, st, a);
@@ -582,6 +581,15 @@ static int run_wgrad(const float* dlt, int ldd, int M, const float* x, int ldx, 
                        delta_is_wide ? 0 : 1);
     MN_LAUNCH_CHECK("reduce_partial_kernel");
     return MI_NERF_OK;
+}
+
+// stand-alone product dW = delta^T x input (+ column sums of delta) for tests and the bench's roofline leg
+int wgrad_product(const float* dlt, int ldd, int M, const float* x, int ldx, int N, int64_t P, float* out, int ldo, float* bias, void* scratch,
+                  size_t scratch_bytes, hipStream_t st) {
+    MN_CHECK_ARG(P >= 1 && M >= 1 && N >= 1 && ldd >= M && ldx >= N && ldo >= N, "bad sizes P=%lld M=%d N=%d", (long long)P, M, N);
+    MN_CHECK_ARG(dlt && x && out && scratch, "NULL device pointer");
+    MN_CHECK_ARG(scratch_bytes >= WGRAD_PARTIAL_FLOATS * 4, "scratch too small: %zu < %zu", scratch_bytes, WGRAD_PARTIAL_FLOATS * 4);
+    return run_wgrad(dlt, ldd, M, x, ldx, N, P, out, ldo, bias, (float*)scratch, st);
 }
 
 template <int W>

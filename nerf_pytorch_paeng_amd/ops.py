@@ -348,6 +348,25 @@ def mlp_backward(net: Net, packed: torch.Tensor, packed_bwd: torch.Tensor, rays:
     return grads, work
 
 
+def wgrad_product(delta: torch.Tensor, M: int, x: torch.Tensor, N: int, P: int, want_bias: bool = True, iters: int = 1, timed: bool = False):
+    """out[M,N] = delta[:P,:M]^T x[:P,:N] (+ bias[M] = column sums of delta) with the backward pass's own kernels.
+    ``delta`` / ``x`` are 2-D row-major with at least P rows (wide operands: 60 rows of slack past P).  Returns
+    (out, bias, avg_ms) -- avg_ms only when ``timed``."""
+    dev = delta.device
+    if delta.dim() != 2 or x.dim() != 2 or delta.shape[0] < P or x.shape[0] < P or delta.shape[1] < M or x.shape[1] < N:
+        raise MiNerfError(f"operands {tuple(delta.shape)} / {tuple(x.shape)} too small for P={P}, M={M}, N={N}")
+    out = torch.empty(M, N, dtype=torch.float32, device=dev)
+    bias = torch.empty(M, dtype=torch.float32, device=dev) if want_bias else None
+    lay = train_layout(make_net(8, 256), 1, 1)
+    scratch = torch.empty(lay.work_bytes - lay.partial, dtype=torch.uint8, device=dev)
+    ms = C.c_float(0.0)
+    with _guard(dev):
+        check(lib().mi_nerf_wgrad_product(dev_ptr(delta, "delta"), delta.stride(0), int(M), dev_ptr(x, "x"), x.stride(0), int(N), int(P), dev_ptr(out),
+                                          N, dev_ptr(bias), dev_ptr(scratch, "scratch", torch.uint8, 16), scratch.numel(), int(iters),
+                                          C.byref(ms) if timed else None, stream_ptr(dev)), "mi_nerf_wgrad_product")
+    return out, bias, (float(ms.value) if timed else None)
+
+
 def train_views(net: Net, n_rays: int, S: int, stash: Optional[torch.Tensor] = None, work: Optional[torch.Tensor] = None):
     """Named float views into the stash / backward workspace (staged parity checks)."""
     lay = train_layout(net, n_rays, S)

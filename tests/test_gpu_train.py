@@ -273,3 +273,20 @@ def test_fine_loss_does_not_reach_coarse_network():
     torch.mean((out["rgb_f"] - target.to(DEV)) ** 2).backward()
     for k, p in model.named_parameters():
         assert (p.grad is None) == k.startswith("model_coarse."), k
+
+
+@pytest.mark.parametrize("P,M,N", [(5000, 256, 256), (4099, 128, 256), (3001, 256, 63), (777, 128, 27), (2500, 3, 128), (1999, 1, 256), (11, 256, 256)])
+def test_wgrad_product_vs_float64(P, M, N):
+    """One weight-gradient product on its own (mi_nerf_wgrad_product) against a float64 matmul: every operand shape of the
+    network, point counts that are not multiples of the 12-row load group."""
+    g = torch.Generator().manual_seed(P + M)
+    ldd = 256 if M > 4 else 4                      # d_raw has a row pitch of 4 floats
+    ldx = 90 if N in (63, 27) else (256 if N > 128 else 128)
+    d = torch.randn(P + 64, ldd, generator=g)
+    x = torch.randn(P + 64, ldx, generator=g)
+    d[P:] = float("nan")                           # rows past P must not contribute
+    x[P:] = float("nan")
+    want = d[:P, :M].double().T @ x[:P, :N].double()
+    out, bias, _ = ops.wgrad_product(d.to(DEV), M, x.to(DEV), N, P)
+    assert rel_err(out, want.float()) < 2e-6 * max(1.0, P ** 0.5 / 10)
+    assert rel_err(bias, d[:P, :M].double().sum(0).float()) < 1e-5
