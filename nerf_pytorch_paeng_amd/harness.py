@@ -253,3 +253,45 @@ def sample_rays_and_pixel(i, img_w, img_h, K, pose, target_img, opts, generator:
     rays_o, rays_d = ops.make_o_d_pixels(int(img_w), int(img_h), K, pose, pix)
     target = target_img.reshape(-1, 3)[pix]
     return rays_o, rays_d, target
+
+
+def train(idx, i_train, images, gt_cam_param, hw, model, criterion, posenc, optimizer, global_batch_idx, vis, opts, *,
+          log_dir: Optional[str] = None, generator: Optional[torch.Generator] = None) -> Dict:
+    """Counterpart of train.py:12-119 with the reference's signature: one optimisation step through the training path.
+    Ray/pixel selection: the global-batch cursor (train.py:25-32) or per-image sampling (train.py:35-45, here without the
+    full-frame ``make_o_d``); render with gradients (train.py:53); ``criterion`` on the coarse and fine colours
+    (train.py:60-66); ``loss.backward(); optimizer.step()`` (train.py:69-70); checkpoint in the reference's format every
+    ``opts.idx_save`` steps when ``log_dir`` is given (train.py:105-114).  ``vis`` (visdom) is accepted and unused.
+    Returns the losses and PSNRs as 0-dim device tensors (no host synchronisation)."""
+    model.train()
+    img_h, img_w = hw
+    gt_intrinsic, gt_extrinsic = gt_cam_param
+    dev = next(model.parameters()).device
+    if global_batch_idx is not None and getattr(opts, "global_batch", True):
+        i_batch, rays_rgb, _ = global_batch_idx(int(opts.N_rays))
+        batch = rays_rgb[i_batch - int(opts.N_rays):i_batch]                                  # [B, 3, 3]   train.py:29
+        rays_o, rays_d, target_img = batch[:, 0], batch[:, 1], batch[:, 2]
+    else:
+        i_img = int(np.random.choice(i_train))                                                # train.py:37
+        target_full = as_f32_dev(torch.as_tensor(images[i_img]), dev)
+        pose = torch.as_tensor(np.asarray(gt_extrinsic[i_img]) if not isinstance(gt_extrinsic, torch.Tensor) else gt_extrinsic[i_img])
+        rays_o, rays_d, target_img = sample_rays_and_pixel(idx, img_w, img_h, gt_intrinsic, pose[:3, :4], target_full, opts, generator)
+    rgb_c, _, rgb_f, _ = NP.batchify_rays_and_render_by_chunk(rays_o.contiguous(), rays_d.contiguous(), model, posenc, img_h, img_w,
+                                                              gt_intrinsic, opts)                # train.py:53
+    optimizer.zero_grad()
+    target_img = target_img.contiguous()
+    loss = criterion(rgb_c, target_img)                                                       # train.py:60
+    out = {"loss_c": loss.detach(), "psnr_c": -10.0 * torch.log10(loss.detach())}
+    if int(opts.N_samples_f) > 0:
+        loss_f = criterion(rgb_f, target_img)
+        out.update(loss_f=loss_f.detach(), psnr_f=-10.0 * torch.log10(loss_f.detach()))
+        loss = loss + loss_f                                                                  # train.py:66
+    out["loss"] = loss.detach()
+    loss.backward()                                                                           # train.py:69
+    optimizer.step()                                                                          # train.py:70
+    if log_dir is not None and idx % int(getattr(opts, "idx_save", 0) or (1 << 62)) == 0 and idx > 0:
+        save_path = os.path.join(log_dir, opts.exp_name)
+        os.makedirs(save_path, exist_ok=True)
+        torch.save({"idx": idx, "model_state_dict": model.state_dict(), "optimizer_state_dict": optimizer.state_dict()},
+                   _ckpt_path(log_dir, opts.exp_name, idx))                                   # train.py:105-114
+    return out
