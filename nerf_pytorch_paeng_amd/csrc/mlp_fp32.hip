@@ -33,6 +33,10 @@ struct MlpArgs {
     float* out;               // [n_pts, 4]
     long long n_wtiles;       // 32-point wave tiles
     long long n_pts;          // MODE 1
+    // MODE 0 tile walk of one wave: start at wave id w (ray-major: ray w, chunk 0; tile-major: tile w), then per step
+    // (ray, chunk) += (walk_ray, walk_chunk), chunk overflow carries walk_carry rays.  n_iter steps for every wave.
+    long long n_rays, walk_ray, walk_carry, n_iter;
+    int walk_chunk, ray_major;
     int S;                    // MODE 0
     int tpr;                  // MODE 0: wave tiles per ray = ceil(S / 32)
     int D;
@@ -132,10 +136,14 @@ void mlp_fp32_kernel(const MlpArgs a) {
     unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tprev = mn_stamp();
 #endif
-    // MODE 0 tile walk without a 64-bit division per tile: wave tile wt = (ray, chunk) advances by gridDim*4 per step.
+    // MODE 0 tile walk without a 64-bit division per tile.  Large batches walk RAY-MAJOR: a wave takes whole rays (ray w,
+    // w + #waves, ...) and their 32-sample chunks back to back, so the per-ray work of the prologue (view-direction
+    // encoding and its hoisted linear_d term, ~550 VALU per lane) is done once per ray instead of once per tile.  Small
+    // batches keep the tile-major walk (tile w, w + #waves, ...), which spreads few rays over more workgroups.
     // The inputs of the NEXT tile (six ray scalars, one depth per lane) are loaded a whole tile ahead.
-    long long t_ray = 0, step_ray = 0;
-    int t_chunk = 0, step_chunk = 0;
+    long long t_ray = 0;
+    int t_chunk = 0;
+    long long bias_ray = -1;            // ray whose hoisted direction term sits in `scratch`
     float nx_o[3] = {0.f, 0.f, 0.f}, nx_d[3] = {0.f, 0.f, 0.f}, nx_z = 0.f;
     auto tile_inputs = [&](long long ray, int chunk) __attribute__((always_inline)) {
         const int sample = chunk * 32 + col;
@@ -144,70 +152,78 @@ void mlp_fp32_kernel(const MlpArgs a) {
         nx_o[0] = rp[0]; nx_o[1] = rp[1]; nx_o[2] = rp[2]; nx_d[0] = rp[3]; nx_d[1] = rp[4]; nx_d[2] = rp[5];
         nx_z = a.z[ray * a.S + sc];
     };
+    const long long wid = (long long)blockIdx.x * 4 + wave;
     if constexpr (MODE == 0) {
-        long long wt0 = (long long)blockIdx.x * 4 + wave;
-        if (wt0 >= a.n_wtiles) wt0 = a.n_wtiles - 1;
-        t_ray = wt0 / a.tpr;
-        t_chunk = (int)(wt0 - t_ray * a.tpr);
-        const long long step = (long long)gridDim.x * 4;
-        step_ray = step / a.tpr;
-        step_chunk = (int)(step - step_ray * a.tpr);
-        tile_inputs(t_ray, t_chunk);
+        if (a.ray_major) { t_ray = wid; t_chunk = 0; }
+        else { t_ray = wid / a.tpr; t_chunk = (int)(wid - t_ray * a.tpr); }
+        const bool in = t_ray < a.n_rays;
+        tile_inputs(in ? t_ray : a.n_rays - 1, in ? t_chunk : a.tpr - 1);
     }
-    for (long long wgt = blockIdx.x; wgt < n_wg_tiles; wgt += gridDim.x) {
-        long long wt = wgt * 4 + wave;
+    for (long long it = 0; it < a.n_iter; ++it) {
 #ifdef MN_DIAG
-        ring.dlog = (a.diag && wgt == (long long)blockIdx.x + 2 * gridDim.x && blockIdx.x < 4) ? a.diag + (size_t)gridDim.x * 32 + ((size_t)blockIdx.x * 4 + wave) * 512 : nullptr;
+        ring.dlog = (a.diag && it == 2 && blockIdx.x < 4) ? a.diag + (size_t)gridDim.x * 32 + ((size_t)blockIdx.x * 4 + wave) * 512 : nullptr;
         ring.dcnt = 0;
 #endif
-        const bool wave_active = wt < a.n_wtiles;
-        if (!wave_active) wt = a.n_wtiles - 1;
+        bool wave_active;
+        long long wt;
         bool valid;
         long long out_idx;
         float de[KDE];
         if constexpr (MODE == 0) {
-            const long long ray = t_ray;
-            const int sample = t_chunk * 32 + col;
+            wave_active = t_ray < a.n_rays;
+            const long long ray = wave_active ? t_ray : a.n_rays - 1;          // the tail recomputes the last tile
+            const int chunk = wave_active ? t_chunk : a.tpr - 1;
+            wt = ray * a.tpr + chunk;
+            const int sample = chunk * 32 + col;
             valid = wave_active && sample < a.S;
             const int sc = sample < a.S ? sample : a.S - 1;
             out_idx = ray * a.S + sc;
             const float ox = nx_o[0], oy = nx_o[1], oz = nx_o[2], dx = nx_d[0], dy = nx_d[1], dz = nx_d[2];
             const float zv = nx_z;
-            // advance to this wave's next tile and start loading its inputs now (clamped: the tail re-reads the last tile)
-            t_ray += step_ray;
-            t_chunk += step_chunk;
-            if (t_chunk >= a.tpr) { t_chunk -= a.tpr; t_ray += 1; }
-            if (t_ray * a.tpr + t_chunk >= a.n_wtiles) { t_ray = (a.n_wtiles - 1) / a.tpr; t_chunk = (int)((a.n_wtiles - 1) - t_ray * a.tpr); }
-            tile_inputs(t_ray, t_chunk);
+            // advance to this wave's next tile and start loading its inputs now
+            t_ray += a.walk_ray;
+            t_chunk += a.walk_chunk;
+            if (t_chunk >= a.tpr) { t_chunk -= a.tpr; t_ray += a.walk_carry; }
+            {
+                const bool in = t_ray < a.n_rays;
+                tile_inputs(in ? t_ray : a.n_rays - 1, in ? t_chunk : a.tpr - 1);
+            }
             // pts = rays_o + rays_d * z : separate multiply and add (nerf_process.py:69-70), no contraction
             const float p[3] = {ox + dx * zv, oy + dy * zv, oz + dz * zv};
             const float amax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(p[0]), __builtin_fabsf(p[1])), __builtin_fabsf(p[2])) * (float)(1 << (LX - 1));
             if (__builtin_expect(amax < SINCOS_FAST_LIMIT, 1)) encode_regs<LX, false>(pe, p, hh);
             else encode_regs<LX, true>(pe, p, hh);               // huge or non-finite coordinates: libm path
             // hoisted view-direction term of linear_d: scratch[n] = b_d[n] + sum_f Wd[n][W+f] * gamma(d/|d|)[f]
-            const float nrm = __builtin_sqrtf(dx * dx + dy * dy + dz * dz);
-            const float v[3] = {dx / nrm, dy / nrm, dz / nrm};
-            float g[IN_D];
-            g[0] = v[0]; g[1] = v[1]; g[2] = v[2];
+            // (per RAY: kept in this wave's LDS scratch while the wave stays on the ray)
+            if (ray != bias_ray) {
+                bias_ray = ray;
+                const float nrm = __builtin_sqrtf(dx * dx + dy * dy + dz * dz);
+                const float v[3] = {dx / nrm, dy / nrm, dz / nrm};
+                float g[IN_D];
+                g[0] = v[0]; g[1] = v[1]; g[2] = v[2];
 #pragma unroll
-            for (int k = 0; k < LD; ++k)
+                for (int k = 0; k < LD; ++k)
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const float y = v[c] * (float)(1 << k);
-                    g[3 + 6 * k + c] = sin_cos_fast(y, 0);       // |y| <= 2^(LD-1): no fallback needed
-                    g[3 + 6 * k + 3 + c] = sin_cos_fast(y, 1);
+                    for (int c = 0; c < 3; ++c) {
+                        const float y = v[c] * (float)(1 << k);
+                        g[3 + 6 * k + c] = sin_cos_fast(y, 0);       // |y| <= 2^(LD-1): no fallback needed
+                        g[3 + 6 * k + 3 + c] = sin_cos_fast(y, 1);
+                    }
+                const float* wdt = side + a.o_wdir_t;
+                const float* bd = side + a.o_bias_d;
+#pragma unroll
+                for (int n0 = 0; n0 < W / 2; n0 += 64) {
+                    const int n = n0 + lane;
+                    float sacc = bd[n];
+#pragma unroll
+                    for (int f = 0; f < IN_D; ++f) sacc = __builtin_fmaf(wdt[f * (W / 2) + n], g[f], sacc);
+                    scratch[n] = sacc;
                 }
-            const float* wdt = side + a.o_wdir_t;
-            const float* bd = side + a.o_bias_d;
-#pragma unroll
-            for (int n0 = 0; n0 < W / 2; n0 += 64) {
-                const int n = n0 + lane;
-                float s = bd[n];
-#pragma unroll
-                for (int f = 0; f < IN_D; ++f) s = __builtin_fmaf(wdt[f * (W / 2) + n], g[f], s);
-                scratch[n] = s;
             }
         } else {
+            wt = it * ((long long)gridDim.x * 4) + wid;
+            wave_active = wt < a.n_wtiles;
+            if (!wave_active) wt = a.n_wtiles - 1;
             const long long p0 = wt * 32 + col;
             valid = wave_active && p0 < a.n_pts;
             out_idx = p0 < a.n_pts ? p0 : a.n_pts - 1;
@@ -347,7 +363,8 @@ static int num_cus() {
 }
 
 template <int W, int MODE, bool STASH = false>
-static int launch(const MlpArgs& args, long long n_wtiles, hipStream_t st) {
+static int launch(const MlpArgs& args_in, long long n_wtiles, hipStream_t st) {
+    MlpArgs args = args_in;
     const size_t lds = RING_BYTES + (size_t)args.side_floats * 4 + 4 * (W / 2) * 4;
     MN_CHECK_ARG(lds <= 160 * 1024, "LDS budget exceeded: %zu bytes", lds);
     auto kern = mlp_fp32_kernel<W, MODE, 10, 4, STASH>;
@@ -358,6 +375,18 @@ static int launch(const MlpArgs& args, long long n_wtiles, hipStream_t st) {
     }
     const long long n_wg = (n_wtiles + 3) / 4;
     const int grid = (int)(n_wg < (long long)num_cus() ? n_wg : (long long)num_cus());
+    {   // the tile walk (see the kernel): ray-major once every wave of the grid gets at least one whole ray
+        const long long NW = (long long)grid * 4;
+        args.ray_major = (MODE == 0 && args.n_rays >= NW) ? 1 : 0;
+        if (args.ray_major) {
+            args.walk_ray = 0; args.walk_chunk = 1; args.walk_carry = NW;
+            args.n_iter = (args.n_rays + NW - 1) / NW * args.tpr;
+        } else {
+            const long long tpr = MODE == 0 ? args.tpr : 1;
+            args.walk_ray = NW / tpr; args.walk_chunk = (int)(NW % tpr); args.walk_carry = 1;
+            args.n_iter = (n_wg + grid - 1) / grid;
+        }
+    }
 #ifdef MN_DIAG
     {   // diagnostic build: run once with stamps and print the per-segment averages (cycles per tile per wave)
         MlpArgs da = args;
@@ -420,7 +449,7 @@ int mlp_rays_fp32(const mi_nerf_net* net, const void* packed_dev, const float* r
     MlpArgs a{};
     fill_common(a, net, packed_dev, false);
     a.rays = rays_dev; a.z = z_dev; a.out = raw_dev; a.S = S; a.tpr = (S + 31) / 32;
-    a.n_wtiles = (long long)n_rays * a.tpr;
+    a.n_wtiles = (long long)n_rays * a.tpr; a.n_rays = n_rays;
     return net->W == 256 ? launch<256, 0>(a, a.n_wtiles, st) : launch<128, 0>(a, a.n_wtiles, st);
 }
 
@@ -435,7 +464,7 @@ int mlp_rays_fp32_stash(const mi_nerf_net* net, const void* packed_dev, const fl
     MlpArgs a{};
     fill_common(a, net, packed_dev, false);
     a.rays = rays_dev; a.z = z_dev; a.out = raw_dev; a.S = S; a.tpr = (S + 31) / 32;
-    a.n_wtiles = (long long)n_rays * a.tpr;
+    a.n_wtiles = (long long)n_rays * a.tpr; a.n_rays = n_rays;
     a.stash_h = stash_h; a.stash_f = stash_f; a.stash_g = stash_g; a.stash_rows = (long long)n_rays * S;
     a.mask_h = mask_h; a.mask_g = mask_g;
     return net->W == 256 ? launch<256, 0, true>(a, a.n_wtiles, st) : launch<128, 0, true>(a, a.n_wtiles, st);
