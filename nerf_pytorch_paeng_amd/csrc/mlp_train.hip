@@ -144,15 +144,22 @@ void mlp_dgrad_kernel(const DgradArgs a) {
         // ---- trunk, last layer first ----
 #pragma unroll 1
         for (int l = a.D - 1;; --l) {
-            const float ds = (l == a.D - 1) ? dr[3] : 0.0f;
             const unsigned mw[4] = {mhv[0], mhv[1], mhv[2], mhv[3]};
             if (l > 0) mhv = *(const u32x4*)(a.mask_h + (((long long)(l - 1) * a.n_wtiles + wt) * 64 + lane) * 4);   // a layer ahead
+            if (l == a.D - 1) {         // the trunk output also feeds the density head: + dens_w * d sigma (rank 1, VALU)
+                const float ds = dr[3];
 #pragma unroll
-            for (int q = 0; q < 4 * NT; ++q) {
-                const f32x4 wv = *(const f32x4*)(dw + 8 * q + 4 * hh);
+                for (int q = 0; q < 4 * NT; ++q) {
+                    const f32x4 wv = *(const f32x4*)(dw + 8 * q + 4 * hh);
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    h[4 * q + e] = mask_apply(__builtin_fmaf(wv[e], ds, acc[q >> 2][4 * (q & 3) + e]), q, e, mw);    // ReLU'
+                    for (int e = 0; e < 4; ++e)
+                        h[4 * q + e] = mask_apply(__builtin_fmaf(wv[e], ds, acc[q >> 2][4 * (q & 3) + e]), q, e, mw);    // ReLU'
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4 * NT; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) h[4 * q + e] = mask_apply(acc[q >> 2][4 * (q & 3) + e], q, e, mw);          // ReLU'
             }
             float* row = a.delta_h + ((long long)l * a.P + idx) * W + 4 * hh;
             if (l == 0) {

@@ -312,3 +312,43 @@ def test_training_slabs_accumulate_like_one_node(monkeypatch):
     assert torch.equal(rgb_one, rgb_many)
     for k in one:
         assert rel_err(many[k], one[k]) < 5e-5, k                      # same kernels; fp32 sums regrouped (scalar bias gradients cancel heavily)
+
+
+def test_training_path_refuses_what_it_does_not_support():
+    from nerf_pytorch_paeng_amd import nerf_process as NP
+    sd, model, posenc, opts, o, d, t_rand, u, target, cfg = _train_setup(D=4, W=128, n=8, Sc=8, Nf=8)
+    K, H, Wd = synthetic.lego_camera()
+    with pytest.raises(ops.MiNerfError):
+        NP.batchify_rays_and_render_by_chunk(o, d, model, posenc, H, Wd, K, opts, bf16=True)          # training is fp32 only
+    with pytest.raises(ops.MiNerfError):
+        NP.render_rays(torch.cat([o, d], -1), model, posenc, opts, return_intermediates=True)
+    cpu_model = type(model)(4, 128, 63, 27)
+    with pytest.raises(ops.MiNerfError):
+        NP.batchify_rays_and_render_by_chunk(o, d, cpu_model, posenc, H, Wd, K, opts)                 # no CPU fallback
+
+
+def test_llff_training_step_through_ndc():
+    """data_type == 'llff': the NDC warp (nerf_process.py:224-226) precedes the differentiable render; gradients reach both nets."""
+    from nerf_pytorch_paeng_amd import nerf_process as NP
+    sd, model, posenc, opts, o, d, t_rand, u, target, cfg = _train_setup(D=4, W=128, n=40, Sc=16, Nf=16, seed=6)
+    K, H, Wd = synthetic.fern_camera()
+    pose = torch.from_numpy(synthetic.fern_pose()).float()
+    pix = torch.from_numpy(synthetic.pixel_batch(H, Wd, 40, 2)).to(DEV)
+    o, d = ops.make_o_d_pixels(Wd, H, K, pose, pix)
+    opts.data_type, opts.near, opts.far = "llff", 0.0, 1.0
+    rgb_c, _, rgb_f, _ = NP.batchify_rays_and_render_by_chunk(o, d, model, posenc, H, Wd, K, opts, t_rand=t_rand, u=u)
+    (torch.nn.functional.mse_loss(rgb_c, target.to(DEV)) + torch.nn.functional.mse_loss(rgb_f, target.to(DEV))).backward()
+    # same rays through the oracle's NDC warp and render, depths pinned to the product's
+    with torch.no_grad():
+        oo, dd = NP.ndc_rays(H, Wd, float(K[0][0]), 1.0, o, d)
+        rays_ndc = torch.cat([oo, dd], -1).contiguous()
+        z_f = NP.render_rays(rays_ndc, model, posenc, opts, t_rand=t_rand, u=u, return_intermediates=True)["_z_f"]
+    ro, rd = R.ndc_rays(H, Wd, float(K[0][0]), 1.0, o.cpu(), d.cpu())
+    psd = {k: torch.as_tensor(v).clone().float().requires_grad_(True) for k, v in sd.items()}
+    cfg = R.PathConfig(near=0.0, far=1.0, N_samples_c=16, N_samples_f=16, perturb=1.0, netDepth=4, netWidth=128, data_type="llff")
+    ref = R.render_rays(torch.cat([ro, rd], -1), psd, cfg, t_rand, u, z_fine_override=z_f.cpu())
+    (torch.mean((ref["rgb_c"] - target) ** 2) + torch.mean((ref["rgb_f"] - target) ** 2)).backward()
+    # un-pinned coarse depths: the forward is ill-conditioned in z (see test_train_step_gradients_match_oracle_autograd),
+    # so this end-to-end comparison through the drop-in surface carries a loose bar
+    for k, p in model.named_parameters():
+        assert p.grad is not None and rel_err(p.grad, psd[k].grad) < 2e-2, k
