@@ -67,6 +67,16 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+def build_variant(tag: str, defines) -> str:
+    """A/B variant libmi_nerf_{tag}.so built with extra -D flags (tools/ab_probe.py times it against the shipped one)."""
+    lib = os.path.join(HERE, f"libmi_nerf_{tag}.so")
+    objs = [_compile(s, False, tuple(defines), "_" + tag) for s in SOURCES]
+    r = subprocess.run([_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", lib], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    return lib
+
+
 def build_diag_library() -> str:
     """Diagnostic variant (-DMN_DIAG: s_memtime stamps per kernel segment).  Never shipped or timed."""
     lib = os.path.join(HERE, "libmi_nerf_diag.so")
@@ -80,5 +90,8 @@ def build_diag_library() -> str:
 if __name__ == "__main__":
     if "--diag" in sys.argv:
         print(build_diag_library())
+    elif "--variant" in sys.argv:                  # python -m ...build --variant TAG -DFOO -DBAR=1
+        i = sys.argv.index("--variant")
+        print(build_variant(sys.argv[i + 1], [a for a in sys.argv[i + 2:] if a.startswith("-D")]))
     else:
         print(build_library(force="--force" in sys.argv, verbose=True))

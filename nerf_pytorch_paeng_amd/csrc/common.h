@@ -53,21 +53,41 @@ __host__ __device__ inline float counter_uniform(uint32_t seed, uint32_t stream_
 // quad_shift 0 -> sin(y), 1 -> cos(y) (cos y = sin(y + pi/2): same reduction, next quadrant).
 // Beyond 2^22 the float multiple count is no longer exact: fall back to the libm path.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float sin_cos_fast(float y, int quad_shift) {
+// The three stages are separate functions so that a caller can spread one evaluation over several instruction groups
+// (mlp_fp32.hip computes the NEXT tile's gamma(x) under the current tile's MFMAs); sin_cos_fast is their composition.
+__device__ __forceinline__ void sc_reduce(float y, int quad_shift, float& r, int& q) {      // Cody-Waite, 3 terms
     const float nf = __builtin_rintf(y * 0.636619772367581343f);
-    float r = __builtin_fmaf(-nf, 1.57079637050628662109375f, y);
+    r = __builtin_fmaf(-nf, 1.57079637050628662109375f, y);
     r = __builtin_fmaf(-nf, -4.371138828673793e-08f, r);
     r = __builtin_fmaf(-nf, -1.7151245100058819e-15f, r);
-    const int q = (int)nf + quad_shift;
-    const float r2 = r * r;
-    float sp = __builtin_fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
+    q = (int)nf + quad_shift;
+}
+__device__ __forceinline__ void sc_poly_sin(float r, float& r2, float& sp) {               // Cephes sinf kernel
+    r2 = r * r;
+    sp = __builtin_fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
     sp = __builtin_fmaf(sp, r2, -1.6666654611e-1f);
     sp = __builtin_fmaf(sp * r2, r, r);
-    float cp = __builtin_fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
+}
+__device__ __forceinline__ void sc_poly_cos(float r2, float& cp) {                          // Cephes cosf kernel
+    cp = __builtin_fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
     cp = __builtin_fmaf(cp, r2, 4.166664568298827e-2f);
     cp = __builtin_fmaf(cp * r2, r2, __builtin_fmaf(-0.5f, r2, 1.0f));
+}
+__device__ __forceinline__ void sc_poly(float r, float& sp, float& cp) {
+    float r2;
+    sc_poly_sin(r, r2, sp);
+    sc_poly_cos(r2, cp);
+}
+__device__ __forceinline__ float sc_select(float sp, float cp, int q) {
     const float v = (q & 1) ? cp : sp;
     return (q & 2) ? -v : v;
+}
+__device__ __forceinline__ float sin_cos_fast(float y, int quad_shift) {
+    float r, sp, cp;
+    int q;
+    sc_reduce(y, quad_shift, r, q);
+    sc_poly(r, sp, cp);
+    return sc_select(sp, cp, q);
 }
 // |y| below this bound keeps the float multiple count exact; callers branch ONCE per point on the largest
 // argument and use the libm path (sinf/cosf, Payne-Hanek) for anything bigger or non-finite.

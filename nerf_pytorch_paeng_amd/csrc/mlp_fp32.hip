@@ -377,7 +377,11 @@ static int launch(const MlpArgs& args_in, long long n_wtiles, hipStream_t st) {
     const int grid = (int)(n_wg < (long long)num_cus() ? n_wg : (long long)num_cus());
     {   // the tile walk (see the kernel): ray-major once every wave of the grid gets at least one whole ray
         const long long NW = (long long)grid * 4;
+#ifdef MN_NO_RAY_MAJOR
+        args.ray_major = 0;                                  // A/B variant (tools/ab_probe.py)
+#else
         args.ray_major = (MODE == 0 && args.n_rays >= NW) ? 1 : 0;
+#endif
         if (args.ray_major) {
             args.walk_ray = 0; args.walk_chunk = 1; args.walk_carry = NW;
             args.n_iter = (args.n_rays + NW - 1) / NW * args.tpr;

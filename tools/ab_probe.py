@@ -1,0 +1,46 @@
+"""A/B timing of the fused MLP kernel: the shipped library against a variant built with
+`python -m nerf_pytorch_paeng_amd.build --variant TAG -D...`, alternating in ONE process on ONE box (box-to-box
+variance is ~0.5 %, more than most single changes):  python tools/ab_probe.py TAG [rounds]"""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+from nerf_pytorch_paeng_amd import _lib, ops, synthetic, weights
+
+tag = sys.argv[1]
+rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+dev = torch.device("cuda:0")
+packed = weights.PackedNeRF.from_state_dict(synthetic.make_state_dict(0, 8, 256), dev)
+K, H, W = synthetic.lego_camera()
+pix = torch.from_numpy(synthetic.pixel_batch(H, W, 4096, 0)).to(dev)
+o, d = ops.make_o_d_pixels(W, H, K, synthetic.pose_spherical(0.0, -30.0, 4.0), pix)
+rays = torch.cat([o, d], -1).contiguous()
+z = torch.sort(torch.rand(4096, 192, device=dev) * 4 + 2, -1)[0]
+raw = torch.empty(4096, 192, 4, device=dev)
+
+libs = {"shipped": _lib.lib()}
+h = C.CDLL(os.path.join(os.path.dirname(_lib.LIB_PATH), f"libmi_nerf_{tag}.so"))
+for name, (res, args) in _lib.SIGNATURES.items():
+    fn = getattr(h, name)
+    fn.restype, fn.argtypes = res, args
+libs[tag] = h
+
+
+def time(lib, iters=20):
+    ms = C.c_float(0.0)
+    rc = lib.mi_nerf_time_mlp_rays(C.byref(packed.net), packed.fine.data_ptr(), rays.data_ptr(), z.data_ptr(), 4096, 192, raw.data_ptr(), iters, 0,
+                                   C.byref(ms), torch.cuda.current_stream(dev).cuda_stream)
+    assert rc == 0
+    return ms.value
+
+
+for lib in libs.values():
+    time(lib, 3)
+res = {k: [] for k in libs}
+for _ in range(rounds):
+    for k, lib in libs.items():
+        res[k].append(time(lib))
+for k, v in res.items():
+    print(f"{k:10s} fine-net launch: min {min(v):.4f} ms  median {sorted(v)[len(v) // 2]:.4f} ms   {[round(x, 4) for x in v]}")
