@@ -94,7 +94,11 @@ void mlp_fp32_kernel(const MlpArgs a) {
     constexpr int KPE = pe_ksteps(LX);  // 32
     constexpr int KDE = pe_ksteps(LD);  // 16
     constexpr int IN_X = 3 + 6 * LX, IN_D = 3 + 6 * LD;
+#ifdef MN_AL_INF
+    constexpr int AL = STASH ? 8 : MN_AL_INF;   // A/B variant (tools/ab_probe.py)
+#else
     constexpr int AL = STASH ? 8 : 4;         // ring_advance<ALLOW>: the training forward interleaves row stores with the DMAs
+#endif
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* side = (float*)(smem + RING_BYTES);
     const int tid = threadIdx.x;
@@ -259,7 +263,7 @@ void mlp_fp32_kernel(const MlpArgs a) {
                     *(u32x4*)(a.mask_h + (((long long)(l - 1) * a.n_wtiles + wt) * 64 + lane) * 4) = m;
                 }
             } else {
-                gemm_part<NT, HN, NT>(acc, h, aq, smem, ring, lane);
+                gemm_part<NT, HN, NT, AL>(acc, h, aq, smem, ring, lane);
             }
         }
         acc_to_b<NT, true>(acc, h);
@@ -283,7 +287,7 @@ void mlp_fp32_kernel(const MlpArgs a) {
                 *(u32x4*)(a.mask_h + (((long long)(a.D - 1) * a.n_wtiles + wt) * 64 + lane) * 4) = m;
             }
         } else {
-            gemm_part<NT, HN, NT / 2>(acc, h, aq, smem, ring, lane);
+            gemm_part<NT, HN, NT / 2, AL>(acc, h, aq, smem, ring, lane);
         }
         acc_to_b<NT, false>(acc, h);
         MN_STAMP(3);   // density head + feature layer
@@ -297,7 +301,7 @@ void mlp_fp32_kernel(const MlpArgs a) {
                 };
                 gemm_part<NT / 2, HN, NT, AL>(acc, h, aq, smem, ring, lane, hook);
             } else {
-                gemm_part<NT / 2, HN, NT>(acc, h, aq, smem, ring, lane);
+                gemm_part<NT / 2, HN, NT, AL>(acc, h, aq, smem, ring, lane);
             }
         } else {
             acc_init<NT / 2>(acc, side + a.o_bias_d, hh);
