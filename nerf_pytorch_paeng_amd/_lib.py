@@ -12,7 +12,8 @@ from typing import Optional
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmi_nerf.so")
+# MI_NERF_LIB: an A/B variant built by `python -m nerf_pytorch_paeng_amd.build --variant TAG ...` (same ABI, same checks)
+LIB_PATH = os.environ.get("MI_NERF_LIB") or os.path.join(HERE, "libmi_nerf.so")
 ABI_VERSION = 1
 
 
