@@ -94,6 +94,12 @@ void mlp_fp32_kernel(const MlpArgs a) {
     constexpr int KPE = pe_ksteps(LX);  // 32
     constexpr int KDE = pe_ksteps(LD);  // 16
     constexpr int IN_X = 3 + 6 * LX, IN_D = 3 + 6 * LD;
+    // groups (t) of a k-quad that carry the training hooks: ReLU' bits, their merge, the row store
+#if defined(MN_HK_B)
+    constexpr int HK_B = MN_HK_B, HK_M = MN_HK_M, HK_S = MN_HK_S;          // A/B variant
+#else
+    constexpr int HK_B = NT - 3, HK_M = NT - 2, HK_S = NT - 1;
+#endif
 #ifdef MN_AL_INF
     constexpr int AL = STASH ? 8 : MN_AL_INF;   // A/B variant (tools/ab_probe.py)
 #else
@@ -253,9 +259,9 @@ void mlp_fp32_kernel(const MlpArgs a) {
                 unsigned mw[4] = {0u, 0u, 0u, 0u};
                 unsigned mb[4];
                 auto hook = [&](int kq, int t) __attribute__((always_inline)) {
-                    if (t == NT - 1) store_chunk(h, kq, row);
-                    else if (t == NT - 2) mask_merge_chunk(mb, kq, mw);
-                    else if (t == NT - 3) mask_bits_chunk(h, kq, mb);
+                    if (t == HK_B) mask_bits_chunk(h, kq, mb);
+                    if (t == HK_M) mask_merge_chunk(mb, kq, mw);
+                    if (t == HK_S) store_chunk(h, kq, row);
                 };
                 gemm_part<NT, HN, NT, AL>(acc, h, aq, smem, ring, lane, hook);
                 if (wave_active) {
@@ -277,9 +283,9 @@ void mlp_fp32_kernel(const MlpArgs a) {
             unsigned mw[4] = {0u, 0u, 0u, 0u};
             unsigned mb[4];
             auto hook = [&](int kq, int t) __attribute__((always_inline)) {
-                if (t == NT - 1) store_chunk(h, kq, row);
-                else if (t == NT - 2) mask_merge_chunk(mb, kq, mw);
-                else if (t == NT - 3) mask_bits_chunk(h, kq, mb);
+                if (t == HK_B) mask_bits_chunk(h, kq, mb);
+                if (t == HK_M) mask_merge_chunk(mb, kq, mw);
+                if (t == HK_S) store_chunk(h, kq, row);
             };
             gemm_part<NT, HN, NT / 2, AL>(acc, h, aq, smem, ring, lane, hook);
             if (wave_active) {
