@@ -212,6 +212,23 @@ def test_mlp_rays_fused_vs_oracle(packed_big, lego_rays, S):
     close(raw2, raw, 2e-4, 1e-4)
 
 
+@pytest.mark.parametrize("n,S", [(1500, 70), (4096, 33), (1024, 64), (1023, 64)])
+def test_mlp_rays_walks_agree(packed_big, lego_rays, n, S):
+    """Ray-major walk (n >= 4 x grid: whole rays per wave, the view-direction term kept across a ray's chunks), tile-major walk
+    (smaller n) and the unfused route must give the same numbers: every ray is evaluated alone as a 1-ray batch (always
+    tile-major) and compared bit for bit with its rows in the big launch; ragged n, odd tiles per ray, partial last tiles."""
+    rays = lego_rays[:n].contiguous()
+    z = torch.sort(torch.rand(n, S, generator=torch.Generator().manual_seed(n + S)) * 4 + 2, -1)[0].to(DEV)
+    raw = ops.mlp_rays(packed_big.net, packed_big.fine, rays, z)
+    assert torch.isfinite(raw).all()
+    for i in (0, 1, n // 3, n // 2 + 1, n - 2, n - 1):
+        one = ops.mlp_rays(packed_big.net, packed_big.fine, rays[i:i + 1].contiguous(), z[i:i + 1].contiguous())
+        assert torch.equal(one[0], raw[i]), i
+    # the training forward walks the same way and stores the same raw
+    raw_t, _ = ops.mlp_rays_train(packed_big.net, packed_big.fine, rays, z)
+    assert torch.equal(raw_t, raw)
+
+
 @pytest.mark.parametrize("S", [64, 192])
 def test_composite_F7(golden, S):
     g = golden("F7_post_process")
