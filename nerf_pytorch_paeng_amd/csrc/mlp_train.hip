@@ -1,17 +1,21 @@
 // mlp_train.hip -- backward pass of the NeRF MLP on fp32 MFMA (gfx950): what `loss.backward()` does for
 // model/NeRF.py:33-52 inside train.py:53-70.
 //
-// Three kernels, all fed from the row-major activation stash the training forward keeps (mlp_fp32.hip, STASH):
-//   * mlp_dgrad_kernel   backward-data chain.  Same register-resident design as the forward kernel: a wave owns 32
-//                        points, the gradient w.r.t. a layer's output sits in the MFMA accumulators, is masked by the
-//                        stashed post-ReLU activation (ReLU') and is directly the B operand of the next (transposed)
-//                        GEMM.  The TRANSPOSED weights stream through the same LDS ring (pack.cpp: pack_bwd_fp32).
-//                        Writes the pre-activation gradient ("delta") of every layer row-major.
-//   * wgrad_kernel       dW[m][n] = sum_p delta[p][m] * input[p][n]: the contraction runs over POINTS, so both MFMA
-//                        operands are plain row-major reads (lane = feature, k = point).  One workgroup accumulates a
-//                        whole 256x256 block (16 accumulator tiles per wave) over a slice of the points; bias
-//                        gradients are column sums of the same operand, accumulated on the VALU under the MFMAs.
+// Kernels, fed from what the training forward keeps (mlp_fp32.hip, STASH: row-major activations + ReLU' bit masks):
+//   * mlp_dgrad_kernel     backward-data chain.  Same register-resident design as the forward kernel: a wave owns 32
+//                          points, the gradient w.r.t. a layer's output sits in the MFMA accumulators, is masked with the
+//                          forward's ReLU' bits (one coalesced 16-byte load per lane per layer) and is directly the B
+//                          operand of the next (transposed) GEMM.  The TRANSPOSED weights stream through the same LDS
+//                          ring (pack.cpp: pack_bwd_fp32).  Every layer's pre-activation gradient ("delta") row is
+//                          written by the GEMM that consumes it, one store per k-quad.
+//   * wgrad_big_kernel     dW[m][n] = sum_p delta[p][m] * input[p][n] for the W-wide layers: the contraction runs over
+//                          POINTS, so both MFMA operands are plain row-major reads (lane = feature, k = point).  One
+//                          workgroup accumulates a whole 256x256 block (16 accumulator tiles per wave) over its share of
+//                          the points; bias gradients are column sums of the same operand on the VALU under the MFMAs.
+//   * wgrad_narrow_kernel  the products with a narrow side (encoded inputs, colour / density gradients): a wave owns
+//                          the whole output, the workgroup's four waves add up through LDS.
 //   * reduce_partial_kernel  deterministic slice reduction into the parameter-gradient vector.
+//   * pack_apply_kernel    device-side re-pack of the weight blobs after optimizer.step().
 // Nothing is differentiated w.r.t. the sample positions or view directions: the reference's only trainable
 // tensors are the MLP parameters (train.py:149-152).
 #include <vector>
