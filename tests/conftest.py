@@ -15,6 +15,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _built_library():
+    """The product has no fallback, so even the CPU tests (symbol export, host packer) need libmi_nerf.so: build it when the
+    tree is fresh (hipcc cross-compiles gfx950 without a GPU; a no-op when the library is up to date)."""
+    from nerf_pytorch_paeng_amd.build import build_library
+    return build_library()
+
+
 def load_golden(name):
     return dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
 
