@@ -204,9 +204,10 @@ int mi_nerf_mlp_backward(const mi_nerf_net* net, const void* packed_dev, const v
 /* One weight-gradient product of the backward pass on its own: out[M, ldo] = delta[P, ldd]^T x[P, ldx] (first M / N columns),
  * bias[M] = column sums of delta (may be NULL) -- what autograd computes for one nn.Linear (model/NeRF.py:24-30).  The wide
  * operands of the network's own products (M, N > 64) must be 16-byte aligned with pitches of 4 floats and are read up to 60
- * rows past P (give them 128 KiB of slack, as mi_nerf_train_layout does).  scratch: mi_nerf_train_layout.work_bytes -
- * .partial bytes.  iters launches back to back; avg_ms_out (may be NULL) = their average device time by hipEvents on
- * `stream` (bench.py's roofline leg for the training kernels; synchronises the stream when given). */
+ * rows past P (give them 128 KiB of slack, as mi_nerf_train_layout does).  scratch: mi_nerf_wgrad_scratch_bytes() bytes.
+ * iters launches back to back; avg_ms_out (may be NULL) = their average device time by hipEvents on `stream`
+ * (bench.py's roofline leg for the training kernels; synchronises the stream when given). */
+size_t mi_nerf_wgrad_scratch_bytes(void);
 int mi_nerf_wgrad_product(const float* delta_dev, int ldd, int M, const float* x_dev, int ldx, int N, int64_t P, float* out_dev,
                           int ldo, float* bias_dev, void* scratch_dev, size_t scratch_bytes, int iters, float* avg_ms_out,
                           void* stream);

@@ -32,6 +32,7 @@ int mlp_backward_fp32(const mi_nerf_net*, const void*, const void*, const float*
                       size_t, float*, int, hipStream_t);
 int train_layout(const mi_nerf_net*, int64_t, int, mi_nerf_train_layout*);
 int wgrad_product(const float*, int, int, const float*, int, int, int64_t, float*, int, float*, void*, size_t, hipStream_t);
+size_t wgrad_scratch_bytes();
 int pack_apply(const int32_t*, const float*, size_t, void*, hipStream_t);
 int pack_bwd_fp32(const mi_nerf_net*, const mi_nerf_params*, void*, size_t);
 size_t packed_bytes_bwd(const mi_nerf_net*);
@@ -305,6 +306,7 @@ int mi_nerf_time_mlp_rays(const mi_nerf_net* net, const void* packed, const floa
     return rc;
 }
 
+size_t mi_nerf_wgrad_scratch_bytes(void) { return wgrad_scratch_bytes(); }
 int mi_nerf_wgrad_product(const float* delta, int ldd, int M, const float* x, int ldx, int N, int64_t P, float* out, int ldo, float* bias,
                           void* scratch, size_t scratch_bytes, int iters, float* avg_ms, void* stream) {
     hipStream_t st = (hipStream_t)stream;

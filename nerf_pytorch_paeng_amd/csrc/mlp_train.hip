@@ -594,6 +594,8 @@ static int run_wgrad(const float* dlt, int ldd, int M, const float* x, int ldx, 
     return MI_NERF_OK;
 }
 
+size_t wgrad_scratch_bytes() { return WGRAD_PARTIAL_FLOATS * 4; }
+
 // stand-alone product dW = delta^T x input (+ column sums of delta) for tests and the bench's roofline leg
 int wgrad_product(const float* dlt, int ldd, int M, const float* x, int ldx, int N, int64_t P, float* out, int ldo, float* bias, void* scratch,
                   size_t scratch_bytes, hipStream_t st) {

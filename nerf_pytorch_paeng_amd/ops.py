@@ -357,8 +357,7 @@ def wgrad_product(delta: torch.Tensor, M: int, x: torch.Tensor, N: int, P: int, 
         raise MiNerfError(f"operands {tuple(delta.shape)} / {tuple(x.shape)} too small for P={P}, M={M}, N={N}")
     out = torch.empty(M, N, dtype=torch.float32, device=dev)
     bias = torch.empty(M, dtype=torch.float32, device=dev) if want_bias else None
-    lay = train_layout(make_net(8, 256), 1, 1)
-    scratch = torch.empty(lay.work_bytes - lay.partial, dtype=torch.uint8, device=dev)
+    scratch = torch.empty(int(lib().mi_nerf_wgrad_scratch_bytes()), dtype=torch.uint8, device=dev)
     ms = C.c_float(0.0)
     with _guard(dev):
         check(lib().mi_nerf_wgrad_product(dev_ptr(delta, "delta"), delta.stride(0), int(M), dev_ptr(x, "x"), x.stride(0), int(N), int(P), dev_ptr(out),
