@@ -186,7 +186,6 @@ struct WgradArgs {
     const float* dlt; int ldd; int M;     // delta [P, ldd]: columns [0, M) of the pointer
     const float* x;   int ldx; int N;     // layer input [P, ldx]: columns [0, N)
     long long P;
-    int pps;                              // points per slice (multiple of 16)
     float* partial;                       // [slices][Mp][Np]
     float* bpartial;                      // [slices][Mp] column sums of delta, or NULL
     int Mp, Np;
@@ -545,7 +544,6 @@ static int run_wgrad(const float* dlt, int ldd, int M, const float* x, int ldx, 
         if (slices > all_groups) slices = (int)all_groups;
         if (slices < 1) slices = 1;
         MN_CHECK_ARG((size_t)slices * per_slice <= WGRAD_PARTIAL_FLOATS, "internal: wgrad partial buffer too small");
-        a.pps = 0;
         a.partial = partial;
         a.bpartial = bias ? partial + (size_t)slices * a.Mp * a.Np : nullptr;
         hipLaunchKernelGGL(wgrad_big_kernel, dim3(slices, by, bz), dim3(256), 0, st, a);
