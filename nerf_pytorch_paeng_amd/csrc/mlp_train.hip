@@ -182,13 +182,19 @@ void mlp_dgrad_kernel(const DgradArgs a) {
 // ---------------------------------------------------------------------------------------------
 // backward weights
 // ---------------------------------------------------------------------------------------------
-struct WgradArgs {
-    const float* dlt; int ldd; int M;     // delta [P, ldd]: columns [0, M) of the pointer
-    const float* x;   int ldx; int N;     // layer input [P, ldx]: columns [0, N)
+constexpr int WG_MAXB = 12;               // products per launch (an 8-layer net has 9 wide ones)
+struct WgradArgs {                        // a BATCH of products of the same point set: blockIdx.y picks the product
+    const float* dlt[WG_MAXB]; const float* x[WG_MAXB];     // delta [P, ldd] (columns [0, M)), layer input [P, ldx] (columns [0, N))
+    int ldd[WG_MAXB], ldx[WG_MAXB], M[WG_MAXB], N[WG_MAXB]; // M, N <= 256
+    int want_bias[WG_MAXB];
     long long P;
-    float* partial;                       // [slices][Mp][Np]
-    float* bpartial;                      // [slices][Mp] column sums of delta, or NULL
-    int Mp, Np;
+    float* partial;                       // [product][slices][256][256]
+    float* bpartial;                      // [product][slices][256] column sums of delta
+    int slices;
+};
+struct ReduceBatch {                      // where each product of a batch goes in the flat gradient vector
+    float* out[WG_MAXB]; float* bias[WG_MAXB];
+    int ldo[WG_MAXB], M[WG_MAXB], N[WG_MAXB];
 };
 
 // masked lanes / rows past the slice end load zeros from here WITHOUT a branch (a value select after the load makes
@@ -205,11 +211,12 @@ void wgrad_big_kernel(const WgradArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 31, kh = lane >> 5;
-    const int m0 = blockIdx.y * 256 + (wave >> 1) * 128;
-    const int n0 = blockIdx.z * 256 + (wave & 1) * 128;
-    const bool aok = m0 + 4 * i < a.M, bok = n0 + 4 * i < a.N;
-    const float* abase = a.dlt + m0 + 4 * i;
-    const float* bbase = a.x + n0 + 4 * i;
+    const int b = blockIdx.y;                                    // product of the batch
+    const int m0 = (wave >> 1) * 128, n0 = (wave & 1) * 128;
+    const bool aok = m0 + 4 * i < a.M[b], bok = n0 + 4 * i < a.N[b];
+    const float* abase = a.dlt[b] + m0 + 4 * i;
+    const float* bbase = a.x[b] + n0 + 4 * i;
+    const long long ldd = a.ldd[b], ldx = a.ldx[b];
 
     f32x16 acc[4][4];
 #pragma unroll
@@ -234,8 +241,8 @@ void wgrad_big_kernel(const WgradArgs a) {
     f32x4 ca[U], cb[U], na[U], nb[U], fa[U], fb[U];
     auto request = [&](f32x4& A, f32x4& B) __attribute__((always_inline)) {
         const bool in = req_row < a.P;
-        const f32x4* qa = (in && aok) ? (const f32x4*)(abase + req_row * a.ldd) : (const f32x4*)g_zero16;
-        const f32x4* qb = (in && bok) ? (const f32x4*)(bbase + req_row * a.ldx) : (const f32x4*)g_zero16;
+        const f32x4* qa = (in && aok) ? (const f32x4*)(abase + req_row * ldd) : (const f32x4*)g_zero16;
+        const f32x4* qb = (in && bok) ? (const f32x4*)(bbase + req_row * ldx) : (const f32x4*)g_zero16;
         A = *qa;
         B = *qb;
         req_row += 2;
@@ -266,20 +273,20 @@ void wgrad_big_kernel(const WgradArgs a) {
         step(fa, fb, na, nb);
     }
     // D[i'][j]: i' = (r&3) + 8*(r>>2) + 4*kh is the A-side lane index, j = lane & 31 the B-side one
-    float* out = a.partial + (size_t)blockIdx.x * a.Mp * a.Np;
+    float* out = a.partial + ((size_t)b * a.slices + blockIdx.x) * (256 * 256);
 #pragma unroll
     for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + 4 * ((r & 3) + 8 * (r >> 2) + 4 * kh) + tm;
             f32x4 v; v[0] = acc[tm][0][r]; v[1] = acc[tm][1][r]; v[2] = acc[tm][2][r]; v[3] = acc[tm][3][r];
-            *(f32x4*)(out + (size_t)m * a.Np + n0 + 4 * i) = v;
+            *(f32x4*)(out + (size_t)m * 256 + n0 + 4 * i) = v;
         }
-    if (a.bpartial && blockIdx.z == 0 && (wave & 1) == 0) {
-        f32x4 s;
+    if (a.want_bias[b] && (wave & 1) == 0) {
+        f32x4 sv;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) s[e] = bsum[e] + __shfl_xor(bsum[e], 32, 64);      // even + odd points of every k-step
-        if (kh == 0) *(f32x4*)(a.bpartial + (size_t)blockIdx.x * a.Mp + m0 + 4 * i) = s;
+        for (int e = 0; e < 4; ++e) sv[e] = bsum[e] + __shfl_xor(bsum[e], 32, 64);      // even + odd points of every k-step
+        if (kh == 0) *(f32x4*)(a.bpartial + ((size_t)b * a.slices + blockIdx.x) * 256 + m0 + 4 * i) = sv;
     }
 }
 
@@ -473,6 +480,40 @@ __global__ __launch_bounds__(256) void reduce_partial_kernel(const float* __rest
     }
 }
 
+// the same for a batch of 256x256-block products (blockIdx.y = product; partial [product][slices][256][256])
+__global__ __launch_bounds__(256) void reduce_batch_kernel(const float* __restrict__ partial, const float* __restrict__ bpartial, int slices,
+                                                            const ReduceBatch rb) {
+    __shared__ float red[4][64];
+    const int b = blockIdx.y;
+    const int M = rb.M[b], N = rb.N[b];
+    const int g = threadIdx.x >> 6, o = threadIdx.x & 63;
+    const int idx = blockIdx.x * 64 + o;
+    const int total = M * N + (rb.bias[b] ? M : 0);
+    float acc = 0.0f;
+    if (idx < M * N) {
+        const int m = idx / N, n = idx - m * N;
+        const float* p = partial + (size_t)b * slices * 65536 + (size_t)m * 256 + n;
+        float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int sl = g;
+        for (; sl + 28 < slices; sl += 32) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s[k] += p[(size_t)(sl + 4 * k) * 65536];
+        }
+        for (; sl < slices; sl += 4) s[0] += p[(size_t)sl * 65536];
+        acc = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    } else if (idx < total) {
+        const int m = idx - M * N;
+        for (int sl = g; sl < slices; sl += 4) acc += bpartial[((size_t)b * slices + sl) * 256 + m];
+    }
+    red[g][o] = acc;
+    __syncthreads();
+    if (g == 0 && idx < total) {
+        const float v = ((red[0][o] + red[1][o]) + red[2][o]) + red[3][o];
+        if (idx < M * N) { const int m = idx / N, n = idx - m * N; rb.out[b][(size_t)m * rb.ldo[b] + n] = v; }
+        else rb.bias[b][idx - M * N] = v;
+    }
+}
+
 // blob[i] = map[i] ? flat[map[i] - 1] : 0      (device-side re-pack after an optimiser step; map from pack_map)
 __global__ __launch_bounds__(256) void pack_apply_kernel(const int32_t* __restrict__ map, const float* __restrict__ flat, long long n,
                                                           float* __restrict__ blob) {
@@ -527,32 +568,48 @@ int train_layout(const mi_nerf_net* net, int64_t n_rays, int S, mi_nerf_train_la
     return MI_NERF_OK;
 }
 
+// A batch of W- or W/2-wide products over the same points in ONE launch: the CUs are split between the products, so every
+// product is cut into num_cus / n slices instead of num_cus -- the partials written and reduced per product (256 KB per
+// slice) shrink by the same factor, and so does the fixed cost that kept a lone 256x256 product at ~75 % of the MFMA peak.
+struct WideProduct { const float* dlt; int ldd, M; const float* x; int ldx, N; float* out; int ldo; float* bias; };
+
+static int run_wgrad_batch(const WideProduct* pr, int n, long long P, float* partial, hipStream_t st) {
+    MN_CHECK_ARG(n >= 1 && n <= WG_MAXB, "internal: %d products in a batch", n);
+    WgradArgs a{};
+    ReduceBatch rb{};
+    int max_total = 0;
+    for (int b = 0; b < n; ++b) {
+        const WideProduct& q = pr[b];
+        MN_CHECK_ARG(q.M <= 256 && q.N <= 256 && q.M % 4 == 0 && q.N % 4 == 0 && q.ldd % 4 == 0 && q.ldx % 4 == 0 &&
+                     ((uintptr_t)q.dlt & 15) == 0 && ((uintptr_t)q.x & 15) == 0,
+                     "internal: wgrad operands must be at most 256 wide, 16-byte aligned, with pitches of 4 floats");
+        a.dlt[b] = q.dlt; a.x[b] = q.x; a.ldd[b] = q.ldd; a.ldx[b] = q.ldx; a.M[b] = q.M; a.N[b] = q.N; a.want_bias[b] = q.bias != nullptr;
+        rb.out[b] = q.out; rb.bias[b] = q.bias; rb.ldo[b] = q.ldo; rb.M[b] = q.M; rb.N[b] = q.N;
+        const int total = q.M * q.N + (q.bias ? q.M : 0);
+        if (total > max_total) max_total = total;
+    }
+    int slices = num_cus_t() / n;                              // one workgroup per CU owns all registers
+    const long long all_groups = (P + 11) / 12;                // groups of 2 x U points, dealt round robin to the slices
+    if (slices > all_groups) slices = (int)all_groups;
+    if (slices < 1) slices = 1;
+    MN_CHECK_ARG((size_t)n * slices * (65536 + 256) <= WGRAD_PARTIAL_FLOATS, "internal: wgrad partial buffer too small");
+    a.P = P; a.slices = slices;
+    a.partial = partial;
+    a.bpartial = partial + (size_t)n * slices * 65536;
+    hipLaunchKernelGGL(wgrad_big_kernel, dim3(slices, n), dim3(256), 0, st, a);
+    MN_LAUNCH_CHECK("wgrad_big_kernel");
+    hipLaunchKernelGGL(reduce_batch_kernel, dim3((max_total + 63) / 64, n), dim3(256), 0, st, (const float*)partial, (const float*)a.bpartial,
+                       slices, rb);
+    MN_LAUNCH_CHECK("reduce_batch_kernel");
+    return MI_NERF_OK;
+}
+
 // one dW (+ optional bias) = delta^T x input, slice partials reduced into `out`
 static int run_wgrad(const float* dlt, int ldd, int M, const float* x, int ldx, int N, long long P, float* out, int ldo, float* bias,
                      float* partial, hipStream_t st) {
-    if (M > 64 && N > 64) {                  // W- or W/2-wide on both sides: 256 x 256 block per workgroup
-        MN_CHECK_ARG(M % 4 == 0 && N % 4 == 0 && ldd % 4 == 0 && ldx % 4 == 0 && ((uintptr_t)dlt & 15) == 0 && ((uintptr_t)x & 15) == 0,
-                     "internal: wgrad operands must be 16-byte aligned with pitches of 4 floats");
-        WgradArgs a{};
-        a.dlt = dlt; a.ldd = ldd; a.M = M; a.x = x; a.ldx = ldx; a.N = N; a.P = P;
-        const int by = (M + 255) / 256, bz = (N + 255) / 256;
-        a.Mp = by * 256; a.Np = bz * 256;
-        int slices = num_cus_t() / (by * bz);              // one workgroup per CU owns all registers
-        const size_t per_slice = (size_t)a.Mp * a.Np + a.Mp;
-        if ((size_t)slices * per_slice > WGRAD_PARTIAL_FLOATS) slices = (int)(WGRAD_PARTIAL_FLOATS / per_slice);
-        const long long all_groups = (P + 11) / 12;        // groups of 2 x U points, dealt round robin to the workgroups
-        if (slices > all_groups) slices = (int)all_groups;
-        if (slices < 1) slices = 1;
-        MN_CHECK_ARG((size_t)slices * per_slice <= WGRAD_PARTIAL_FLOATS, "internal: wgrad partial buffer too small");
-        a.partial = partial;
-        a.bpartial = bias ? partial + (size_t)slices * a.Mp * a.Np : nullptr;
-        hipLaunchKernelGGL(wgrad_big_kernel, dim3(slices, by, bz), dim3(256), 0, st, a);
-        MN_LAUNCH_CHECK("wgrad_big_kernel");
-        const int total = M * N + (bias ? M : 0);
-        hipLaunchKernelGGL(reduce_partial_kernel, dim3((total + 63) / 64), dim3(256), 0, st, (const float*)partial, (const float*)a.bpartial,
-                           slices, a.Mp, a.Np, M, N, out, ldo, bias, a.Mp, 0);
-        MN_LAUNCH_CHECK("reduce_partial_kernel");
-        return MI_NERF_OK;
+    if (M > 64 && N > 64) {                  // W- or W/2-wide on both sides: a batch of one
+        const WideProduct q{dlt, ldd, M, x, ldx, N, out, ldo, bias};
+        return run_wgrad_batch(&q, 1, P, partial, st);
     }
     // one narrow side: the wide operand is whichever has more columns; the partials come out [wide][narrow]
     const bool delta_is_wide = M >= N;
@@ -666,22 +723,33 @@ int mlp_backward_fp32(const mi_nerf_net* net, const void* packed_fwd, const void
     // layer inputs gamma(x), gamma(d) as rows (nerf_process.py:69-85)
     if (int rc = stage_embed(rays, z, n_rays, S, net->L_x, net->L_d, emb, st)) return rc;
     const size_t PW = (size_t)P * W;
-    // trunk
-    if (int rc = run_wgrad(delta_h, W, W, emb, in_all, in_x, P, grads + po.w_x[0], in_x, grads + po.b_x[0], partial, st)) return rc;
-    for (int l = 1; l < D; ++l) {
-        const bool cat = po.in_l[l] != W;
-        const float* dl = delta_h + (size_t)l * PW;
-        float* gw = grads + po.w_x[l];
-        if (cat)
-            if (int rc = run_wgrad(dl, W, W, emb, in_all, in_x, P, gw, po.in_l[l], nullptr, partial, st)) return rc;   // [gamma(x), h]
-        if (int rc = run_wgrad(dl, W, W, stash_h + (size_t)(l - 1) * PW, W, W, P, gw + (cat ? in_x : 0), po.in_l[l], grads + po.b_x[l],
-                               partial, st)) return rc;
-    }
+    // wide products (both sides W or W/2 wide) in one launch: trunk layers 1..D-1 (activation part), linear_feat, linear_d (feature part)
     const float* h_last = stash_h + (size_t)(D - 1) * PW;
-    // heads
-    if (int rc = run_wgrad(delta_f, W, W, h_last, W, W, P, grads + po.w_feat, W, grads + po.b_feat, partial, st)) return rc;
+    {
+        WideProduct pr[WG_MAXB];
+        int n = 0;
+        auto flush = [&]() -> int {
+            const int rc = n ? run_wgrad_batch(pr, n, P, partial, st) : MI_NERF_OK;
+            n = 0;
+            return rc;
+        };
+        for (int l = 1; l < D; ++l) {
+            const bool cat = po.in_l[l] != W;
+            pr[n++] = WideProduct{delta_h + (size_t)l * PW, W, W, stash_h + (size_t)(l - 1) * PW, W, W, grads + po.w_x[l] + (cat ? in_x : 0),
+                                  po.in_l[l], grads + po.b_x[l]};
+            if (n == WG_MAXB) if (int rc = flush()) return rc;
+        }
+        pr[n++] = WideProduct{delta_f, W, W, h_last, W, W, grads + po.w_feat, W, grads + po.b_feat};
+        if (n == WG_MAXB) if (int rc = flush()) return rc;
+        pr[n++] = WideProduct{delta_d, W / 2, W / 2, stash_f, W, W, grads + po.w_d, W + in_d, grads + po.b_d};
+        if (int rc = flush()) return rc;
+    }
+    // products with a narrow side: gamma(x) into layer 0 and the skip layer, gamma(d) into linear_d, the density and colour heads
+    if (int rc = run_wgrad(delta_h, W, W, emb, in_all, in_x, P, grads + po.w_x[0], in_x, grads + po.b_x[0], partial, st)) return rc;
+    for (int l = 1; l < D; ++l)
+        if (po.in_l[l] != W)
+            if (int rc = run_wgrad(delta_h + (size_t)l * PW, W, W, emb, in_all, in_x, P, grads + po.w_x[l], po.in_l[l], nullptr, partial, st)) return rc;
     if (int rc = run_wgrad(d_raw + 3, 4, 1, h_last, W, W, P, grads + po.w_dens, W, grads + po.b_dens, partial, st)) return rc;
-    if (int rc = run_wgrad(delta_d, W / 2, W / 2, stash_f, W, W, P, grads + po.w_d, W + in_d, grads + po.b_d, partial, st)) return rc;
     if (int rc = run_wgrad(delta_d, W / 2, W / 2, emb + in_x, in_all, in_d, P, grads + po.w_d + W, W + in_d, nullptr, partial, st)) return rc;
     if (int rc = run_wgrad(d_raw, 4, 3, stash_g, W / 2, W / 2, P, grads + po.w_color, W / 2, grads + po.b_color, partial, st)) return rc;
     return MI_NERF_OK;
