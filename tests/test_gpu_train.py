@@ -352,3 +352,30 @@ def test_llff_training_step_through_ndc():
     # so this end-to-end comparison through the drop-in surface carries a loose bar
     for k, p in model.named_parameters():
         assert p.grad is not None and rel_err(p.grad, psd[k].grad) < 2e-2, k
+
+
+def test_backward_full_size_properties():
+    """BASELINE config #2 sizes (4096 rays, 64 + 128 samples, 8x256): the oracle's autograd is too slow there, so the backward is
+    checked through properties: bit-reproducible, linear in the incoming gradient, zero for a zero gradient, finite."""
+    net = ops.make_net(8, 256, 4)
+    sd = synthetic.make_state_dict(0, 8, 256)
+    prefix = "model_fine."
+    packed = ops.pack_module(sd, prefix, net).to(DEV)
+    packed_bwd = ops.pack_module(sd, prefix, net, backward=True).to(DEV)
+    K, H, W = synthetic.lego_camera()
+    pix = torch.from_numpy(synthetic.pixel_batch(H, W, 4096, 0)).to(DEV)
+    o, d = ops.make_o_d_pixels(W, H, K, synthetic.pose_spherical(0.0, -30.0, 4.0), pix)
+    rays = torch.cat([o, d], -1).contiguous()
+    z = torch.sort(2.0 + 4.0 * torch.rand(4096, 192, generator=torch.Generator().manual_seed(0)), -1).values.to(DEV)
+    raw, stash = ops.mlp_rays_train(net, packed, rays, z)
+    G = torch.randn(4096, 3, generator=torch.Generator().manual_seed(1)).to(DEV)
+    d_raw = ops.composite_backward(raw, z, rays, G)
+    assert torch.isfinite(d_raw).all()
+    g1, work = ops.mlp_backward(net, packed, packed_bwd, rays, z, d_raw, stash)
+    g1b, _ = ops.mlp_backward(net, packed, packed_bwd, rays, z, d_raw, stash, work)
+    assert torch.isfinite(g1).all() and torch.equal(g1, g1b)                       # deterministic reductions
+    g2, _ = ops.mlp_backward(net, packed, packed_bwd, rays, z, (2.0 * d_raw).contiguous(), stash, work)
+    assert torch.equal(g2, 2.0 * g1)                                                # scaling by 2 is exact in fp32
+    g0, _ = ops.mlp_backward(net, packed, packed_bwd, rays, z, torch.zeros_like(d_raw), stash, work)
+    assert float(g0.abs().max()) == 0.0
+    assert torch.equal(ops.composite_backward(raw, z, rays, 2.0 * G), 2.0 * d_raw)
