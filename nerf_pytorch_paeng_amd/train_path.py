@@ -162,3 +162,21 @@ def render_train(rays: torch.Tensor, model: torch.nn.Module, opts, *, t_rand=Non
     if Nf > 0:
         out["rgb_f"], out["disp_f"] = rgb_f, disp_f
     return out
+
+
+class RenderModule(torch.nn.Module):
+    """``forward(rays_o, rays_d, H, W, K)`` = ``batchify_rays_and_render_by_chunk`` on the wrapped model.
+
+    The reference trains on one GPU (main.py:166-170).  For data-parallel training wrap THIS module, not the NeRF, in
+    ``torch.nn.parallel.DistributedDataParallel``: DDP needs the forward to go through the wrapper, and the NeRF's own
+    ``forward(x, is_fine)`` is the embedded-input call of model/NeRF.py:70-78.  The hand-written backward returns ordinary
+    parameter gradients, so DDP's bucketed all-reduce (RCCL over xGMI with backend "nccl") overlaps with it as usual: the
+    coarse network's gradients are reduced while the fine network's backward is still running."""
+
+    def __init__(self, model: torch.nn.Module, posenc, opts):
+        super().__init__()
+        self.model, self.posenc, self.opts = model, posenc, opts
+
+    def forward(self, rays_o, rays_d, H, W, K, **kw):
+        from . import nerf_process as NP
+        return NP.batchify_rays_and_render_by_chunk(rays_o, rays_d, self.model, self.posenc, H, W, K, self.opts, **kw)
