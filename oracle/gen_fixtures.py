@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generate the golden fixtures F1..F9 by RUNNING THE REFERENCE.
+"""Generate the golden fixtures F1..F10 (F10: the callers either side of the path) by RUNNING THE REFERENCE.
 
 Runs only in the build container (needs /root/reference).  It imports the reference's hot-path
 modules unmodified, drives them on CPU through a small import shim, and writes inputs + the

@@ -6,9 +6,10 @@ the product package ``nerf_pytorch_paeng_amd`` (which has no CPU fallback and fa
 when ``libmi_nerf.so`` is missing).
 
 Parity status: PINNED.  Every function below is checked against tensors captured from the
-reference itself (fixtures F1..F9 under ``tests/golden/``, produced by
+reference itself (fixtures F1..F10 under ``tests/golden/``, produced by
 ``oracle/gen_fixtures.py`` which imports ``/root/reference`` in the build container) and
-against the hand-computed known-answer vectors of SURVEY.md section 8(a).
+against the hand-computed known-answer vectors of SURVEY.md section 8(a).  The training path is checked against
+torch autograd run on these same functions (``fine_z`` detaches like nerf_process.py:66).
 
 All arithmetic is fp32 (torch CPU).  Randomness is always *injected* (``t_rand`` for the
 stratified jitter, ``u`` for the inverse-CDF draw) because the reference draws unseeded
