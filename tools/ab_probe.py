@@ -1,6 +1,6 @@
 """A/B timing of the fused MLP kernel: the shipped library against a variant built with
 `python -m nerf_pytorch_paeng_amd.build --variant TAG -D...`, alternating in ONE process on ONE box (box-to-box
-variance is ~0.5 %, more than most single changes):  python tools/ab_probe.py TAG [rounds]"""
+variance is ~0.5 %, more than most single changes):  python tools/ab_probe.py TAG [rounds] [bf16]"""
 import ctypes as C
 import os
 import sys
@@ -11,6 +11,7 @@ from nerf_pytorch_paeng_amd import _lib, ops, synthetic, weights
 
 tag = sys.argv[1]
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+bf16 = len(sys.argv) > 3 and sys.argv[3] == "bf16"
 dev = torch.device("cuda:0")
 packed = weights.PackedNeRF.from_state_dict(synthetic.make_state_dict(0, 8, 256), dev)
 K, H, W = synthetic.lego_camera()
@@ -30,7 +31,8 @@ libs[tag] = h
 
 def time(lib, iters=20):
     ms = C.c_float(0.0)
-    rc = lib.mi_nerf_time_mlp_rays(C.byref(packed.net), packed.fine.data_ptr(), rays.data_ptr(), z.data_ptr(), 4096, 192, raw.data_ptr(), iters, 0,
+    blob = packed.bf16()[1] if bf16 else packed.fine
+    rc = lib.mi_nerf_time_mlp_rays(C.byref(packed.net), blob.data_ptr(), rays.data_ptr(), z.data_ptr(), 4096, 192, raw.data_ptr(), iters, int(bf16),
                                    C.byref(ms), torch.cuda.current_stream(dev).cuda_stream)
     assert rc == 0
     return ms.value
