@@ -3,14 +3,14 @@
 Same constructor arguments, same sub-module and parameter names (so ``load_state_dict`` accepts the
 reference's checkpoints, train.py:105-114), same ``forward(x, is_fine)`` contract.  The forward pass
 is the hand-written MFMA kernel (``mi_nerf_mlp_embedded``): parameters are packed into the kernel's
-streaming layout on first use and re-packed only when they change.  Forward-only (the callers on the
-path run under ``torch.no_grad()``, test.py:36,140).
+streaming layout on first use and re-packed only when they change.  ``forward`` itself is inference only (its callers
+run under ``torch.no_grad()``, test.py:36,140); training goes through ``nerf_process.batchify_rays_and_render_by_chunk``
+with gradients enabled (train_path.py), which differentiates w.r.t. this module's parameters.
 """
 from __future__ import annotations
 
 from typing import Sequence
 
-import torch
 import torch.nn as nn
 
 from .. import ops

@@ -20,7 +20,6 @@ from __future__ import annotations
 
 from typing import Dict, Optional
 
-import numpy as np
 import torch
 
 from . import ops

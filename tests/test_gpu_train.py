@@ -1,7 +1,6 @@
 """GPU parity of the training path: gradients from the HIP backward kernels,
 called through the C ABI, against torch autograd run on the CPU oracle (oracle/restate.py) with the same inputs.
 Tolerances are stated per test; gradients are compared relative to the largest entry of the same tensor."""
-import numpy as np
 import pytest
 import torch
 
