@@ -11,6 +11,7 @@ from __future__ import annotations
 
 from typing import Sequence
 
+import torch
 import torch.nn as nn
 
 from .. import ops
@@ -53,6 +54,11 @@ class NeRF(nn.Module):
     def forward(self, x, is_fine: bool = False):
         """x [n, input_ch + input_ch_d] -> [n, 4] = cat([rgb_raw, density_raw]) (NeRF.py:51,70-78)."""
         from ..weights import packed_for
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            # never hand back a tensor that silently carries no graph: the differentiable entry is the render path
+            raise MiNerfError("NeRF.forward(x, is_fine) is the inference kernel and records no autograd graph: call it under "
+                              "torch.no_grad() (test.py:36), or train through nerf_process.batchify_rays_and_render_by_chunk / "
+                              "render_rays with gradients enabled (train.py:53)")
         packed = packed_for(self)
         x = as_f32_dev(x, packed.device)
         lead = x.shape[:-1]

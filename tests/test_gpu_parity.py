@@ -168,17 +168,20 @@ def test_mlp_embedded_F6(golden, tag, D, W):
     model.load_state_dict({k: T(v) for k, v in sd.items()})
     model.to(DEV)
     x = g2d(g["x"])
-    for is_fine, net in ((False, "coarse"), (True, "fine")):
-        y = model(x, is_fine=is_fine)
-        ref64 = R.mlp_forward(sd, f"model_{net}.", T(g["x"]), D, 63, 27, dtype=torch.float64)
-        e_ref = err(T(g[f"{tag}_{net}"]), ref64)            # the reference's own fp32 rounding noise
-        e_gpu = err(y, ref64)
-        print(f"{tag} {net}: |gpu-fp64| {e_gpu:.2e}   |reference-fp64| {e_ref:.2e}")
-        assert e_gpu <= max(4 * e_ref, 2e-5)
-        close(y, g[f"{tag}_{net}"], 1e-4, 1e-5)
-    # odd sizes: tail tile, a single row, nothing
-    assert torch.equal(model(x[:37]), model(x)[:37])
-    assert model(x[:1]).shape == (1, 4) and model(x[:0]).shape == (0, 4)
+    with pytest.raises(ops.MiNerfError):                      # grad mode + trainable parameters: no silent graph-less result
+        model(x)
+    with torch.no_grad():
+        for is_fine, net in ((False, "coarse"), (True, "fine")):
+            y = model(x, is_fine=is_fine)
+            ref64 = R.mlp_forward(sd, f"model_{net}.", T(g["x"]), D, 63, 27, dtype=torch.float64)
+            e_ref = err(T(g[f"{tag}_{net}"]), ref64)            # the reference's own fp32 rounding noise
+            e_gpu = err(y, ref64)
+            print(f"{tag} {net}: |gpu-fp64| {e_gpu:.2e}   |reference-fp64| {e_ref:.2e}")
+            assert e_gpu <= max(4 * e_ref, 2e-5)
+            close(y, g[f"{tag}_{net}"], 1e-4, 1e-5)
+        # odd sizes: tail tile, a single row, nothing
+        assert torch.equal(model(x[:37]), model(x)[:37])
+        assert model(x[:1]).shape == (1, 4) and model(x[:0]).shape == (0, 4)
 
 
 def test_mlp_repack_on_weight_change():
@@ -187,10 +190,10 @@ def test_mlp_repack_on_weight_change():
     model.load_state_dict({k: T(v) for k, v in sd.items()})
     model.to(DEV)
     x = torch.rand(64, 90, device=DEV)
-    y0 = model(x)
     with torch.no_grad():
+        y0 = model(x)
         model.model_coarse.linear_color.bias.add_(1.0)
-    y1 = model(x)
+        y1 = model(x)
     close(y1[:, :3] - y0[:, :3], np.ones((64, 3), np.float32), 1e-5)
 
 
