@@ -109,11 +109,34 @@ def pre_process(rays, posenc, opts, z_vals=None, weights=None, isFine=False, *, 
     return embedded, z, rays[:, 3:]
 
 
+class _Composite(torch.autograd.Function):
+    """post_process with the gradient the reference's loss uses: d rgb_map -> d raw (mi_nerf_composite_backward).
+    disp / acc / weights / depth are returned without a graph (train.py:60-66 reads the colours only)."""
+
+    @staticmethod
+    def forward(ctx, raw, z, d):
+        rgb, disp, acc, wts, depth = ops.composite(raw, z, d, want_all=True)
+        ctx.save_for_backward(raw, z, d)
+        ctx.mark_non_differentiable(disp, acc, wts, depth)
+        ctx.set_materialize_grads(False)
+        return rgb, disp, acc, wts, depth
+
+    @staticmethod
+    def backward(ctx, g_rgb, *_):
+        if g_rgb is None:
+            return None, None, None
+        raw, z, d = ctx.saved_tensors
+        return ops.composite_backward(raw, z, d, g_rgb.contiguous().float()), None, None
+
+
 def post_process(outputs, z_vals, rays_d):
-    """Alpha compositing (nerf_process.py:89-140) -> (rgb_map, disp_map, acc_map, weights, depth_map)."""
+    """Alpha compositing (nerf_process.py:89-140) -> (rgb_map, disp_map, acc_map, weights, depth_map).
+    Differentiable in ``rgb_map`` w.r.t. ``outputs`` when they carry a graph."""
     z = as_f32_dev(z_vals)
     raw = as_f32_dev(outputs, z.device)
     d = as_f32_dev(rays_d, z.device)
+    if torch.is_grad_enabled() and raw.requires_grad:
+        return _Composite.apply(raw, z.detach(), d.detach())
     return ops.composite(raw, z, d, want_all=True)
 
 
@@ -122,6 +145,9 @@ raw2outputs = post_process          # north-star alias (original NeRF naming)
 
 def run_network(model, embedded, is_fine: bool = False):
     """north-star alias: the chunked ``model(embedded)`` loop of nerf_process.py:190-192,206-207 as one launch."""
+    if train_path.wants_grad(model):
+        raise MiNerfError("run_network is the inference kernel and records no autograd graph: call it under torch.no_grad(), "
+                          "or train through batchify_rays_and_render_by_chunk / render_rays with gradients enabled")
     packed = packed_for(model)
     return ops.mlp_embedded(packed.net, packed.blob(is_fine), as_f32_dev(embedded, packed.device))
 
