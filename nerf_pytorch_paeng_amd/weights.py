@@ -50,6 +50,7 @@ class PackedNeRF:
         self.net, self.coarse, self.fine = net, coarse, fine
         self._bf16: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
         self._sd = None
+        self._sd_source = None
 
     @property
     def device(self) -> torch.device:
@@ -72,6 +73,9 @@ class PackedNeRF:
     def bf16(self) -> Tuple[torch.Tensor, torch.Tensor]:
         """bf16-stream blobs for the bf16 MFMA variant (packed lazily)."""
         if self._bf16 is None:
+            src = self._sd_source() if self._sd_source is not None else None
+            if self._sd is None and src is not None:
+                self._sd = {k: v.detach().cpu().numpy() for k, v in src.state_dict().items() if k.startswith("model_")}
             if self._sd is None:
                 raise MiNerfError("bf16 packing needs the state dict (keep_state=True)")
             self._bf16 = (ops.pack_module(self._sd, "model_coarse.", self.net, bf16=True).to(self.device),
@@ -107,6 +111,27 @@ def packed_for(model, device=None) -> PackedNeRF:
         device = next(model.parameters()).device
     if torch.device(device).type != "cuda":
         raise MiNerfError(f"model lives on {device}: the MI355X path needs a HIP device (no CPU fallback)")
-    packed = PackedNeRF.from_state_dict(model.state_dict(), device)
+    packed = _pack_module_on_device(model, torch.device(device))
     _cache[model] = (fp, packed)
+    return packed
+
+
+# gather maps per network shape (built once by the host packer, kept on the device)
+_maps: Dict[tuple, torch.Tensor] = {}
+
+
+def _pack_module_on_device(model: torch.nn.Module, device: torch.device) -> PackedNeRF:
+    """Re-pack after a parameter change without leaving the device (an optimizer.step() between two evaluations,
+    main.py:140-149): flatten the parameters, gather them into the blob layout with the cached map."""
+    sd = model.state_dict()
+    net = infer_net(sd)
+    fine_net = infer_net(sd, "model_fine.")
+    if tuple(getattr(net, f) for f, _ in Net._fields_) != tuple(getattr(fine_net, f) for f, _ in Net._fields_):
+        raise MiNerfError("coarse and fine networks differ in shape")
+    key = (tuple(getattr(net, f) for f, _ in Net._fields_), str(device))
+    if key not in _maps:
+        _maps[key] = ops.pack_map(net, False).to(device)
+    blobs = [ops.pack_apply(_maps[key], ops.flatten_params(sd, prefix, net, device)) for prefix in ("model_coarse.", "model_fine.")]
+    packed = PackedNeRF(net, blobs[0], blobs[1])
+    packed._sd_source = weakref.ref(model)   # the bf16 variant is packed on the host, lazily; weak: the cache is keyed by the module
     return packed
