@@ -497,3 +497,19 @@ def test_error_behaviour(packed_big, lego_rays):
         weights.PackedNeRF.from_state_dict(synthetic.make_state_dict(0, 4, 64), DEV)               # unsupported width
     with pytest.raises(MiNerfError):
         NP.render_rays(lego_rays[:4].cpu(), weights.packed_for(packed_big), None, opts, t_rand=torch.rand(4, 63))   # wrong t_rand shape
+
+
+def test_bf16_through_module_model(lego_rays):
+    """nn.Module models are re-packed on the device; their bf16 blobs are packed lazily from the module's state dict."""
+    sd = synthetic.make_state_dict(0, 8, 256)
+    model = NeRF(8, 256, 63, 27).to(DEV)
+    model.load_state_dict({k: T(v) for k, v in sd.items()})
+    packed = weights.PackedNeRF.from_state_dict(sd, DEV)
+    opts = make_opts()
+    rays = lego_rays[:64].contiguous()
+    with torch.no_grad():
+        a = NP.render_rays(rays, model, None, opts, seed=3, bf16=True)
+        b = NP.render_rays(rays, packed, None, opts, seed=3, bf16=True)
+        c = NP.render_rays(rays, model, None, opts, seed=3)
+        d = NP.render_rays(rays, packed, None, opts, seed=3)
+    assert torch.equal(a["rgb_f"], b["rgb_f"]) and torch.equal(c["rgb_f"], d["rgb_f"])
