@@ -201,6 +201,16 @@ int mi_nerf_mlp_backward(const mi_nerf_net* net, const void* packed_dev, const v
                          const float* z_dev, int64_t n_rays, int S, const float* d_raw_dev, const void* stash_dev,
                          void* work_dev, size_t work_bytes, float* grads_dev, int stage, void* stream);
 
+/* The same pair for pre-embedded rows x [n, in_x + in_d]: what autograd does when model(embedded, is_fine) is called directly
+ * with gradients enabled, as the reference's own render_rays does (nerf_process.py:190-192,206-207; model/NeRF.py:70-78) --
+ * for callers that keep the reference's pipeline and swap only the model.  Buffers: mi_nerf_train_layout_query(net,
+ * ceil(n/32), 32).  d_out [n,4] -> grads [mi_nerf_param_count]; nothing is differentiated w.r.t. x. */
+int mi_nerf_mlp_embedded_train(const mi_nerf_net* net, const void* packed_dev, const float* x_dev, int64_t n, float* out_dev,
+                               void* stash_dev, size_t stash_bytes, void* stream);
+int mi_nerf_mlp_embedded_backward(const mi_nerf_net* net, const void* packed_dev, const void* packed_bwd_dev, const float* x_dev,
+                                  int64_t n, const float* d_out_dev, const void* stash_dev, void* work_dev, size_t work_bytes,
+                                  float* grads_dev, void* stream);
+
 /* One weight-gradient product of the backward pass on its own: out[M, ldo] = delta[P, ldd]^T x[P, ldx] (first M / N columns),
  * bias[M] = column sums of delta (may be NULL) -- what autograd computes for one nn.Linear (model/NeRF.py:24-30).  The wide
  * operands of the network's own products (M, N > 64) must be 16-byte aligned with pitches of 4 floats and are read up to 60

@@ -29,7 +29,9 @@ int mlp_rays_bf16(const mi_nerf_net*, const void*, const float*, const float*, i
 int mlp_rays_fp32_stash(const mi_nerf_net*, const void*, const float*, const float*, int64_t, int, float*, float*, float*, float*, unsigned*,
                         unsigned*, hipStream_t);
 int mlp_backward_fp32(const mi_nerf_net*, const void*, const void*, const float*, const float*, int64_t, int, const float*, const void*, void*,
-                      size_t, float*, int, hipStream_t);
+                      size_t, float*, int, hipStream_t, const float*, int64_t);
+int mlp_embedded_fp32_stash(const mi_nerf_net*, const void*, const float*, int64_t, float*, float*, float*, float*, unsigned*, unsigned*,
+                            hipStream_t);
 int train_layout(const mi_nerf_net*, int64_t, int, mi_nerf_train_layout*);
 int wgrad_product(const float*, int, int, const float*, int, int, int64_t, float*, int, float*, void*, size_t, hipStream_t);
 size_t wgrad_scratch_bytes();
@@ -225,7 +227,28 @@ int mi_nerf_mlp_backward(const mi_nerf_net* net, const void* packed, const void*
                          int64_t n_rays, int S, const float* d_raw, const void* stash, void* work, size_t work_bytes, float* grads,
                          int stage, void* st) {
     if (int rc = check_net_basic(net)) return rc;
-    return mlp_backward_fp32(net, packed, packed_bwd, rays, z, n_rays, S, d_raw, stash, work, work_bytes, grads, stage, (hipStream_t)st);
+    return mlp_backward_fp32(net, packed, packed_bwd, rays, z, n_rays, S, d_raw, stash, work, work_bytes, grads, stage, (hipStream_t)st, nullptr, -1);
+}
+int mi_nerf_mlp_embedded_train(const mi_nerf_net* net, const void* packed, const float* x, int64_t n, float* out, void* stash, size_t stash_bytes,
+                               void* st) {
+    if (int rc = check_net_basic(net)) return rc;
+    MN_CHECK_ARG(n >= 0, "bad n=%lld", (long long)n);
+    mi_nerf_train_layout L;
+    if (int rc = train_layout(net, (n + 31) / 32, 32, &L)) return rc;
+    if (n == 0) return MI_NERF_OK;
+    MN_CHECK_ARG(stash != nullptr && stash_bytes >= L.stash_bytes, "stash too small: %zu < %zu", stash_bytes, L.stash_bytes);
+    return mlp_embedded_fp32_stash(net, packed, x, n, out, (float*)((char*)stash + L.stash_h), (float*)((char*)stash + L.stash_f),
+                                   (float*)((char*)stash + L.stash_g), (unsigned*)((char*)stash + L.mask_h), (unsigned*)((char*)stash + L.mask_g),
+                                   (hipStream_t)st);
+}
+int mi_nerf_mlp_embedded_backward(const mi_nerf_net* net, const void* packed, const void* packed_bwd, const float* x, int64_t n, const float* d_out,
+                                  const void* stash, void* work, size_t work_bytes, float* grads, void* st) {
+    if (int rc = check_net_basic(net)) return rc;
+    MN_CHECK_ARG(n >= 0, "bad n=%lld", (long long)n);
+    if (n == 0) return MI_NERF_OK;
+    MN_CHECK_ARG(x != nullptr, "NULL device pointer");
+    return mlp_backward_fp32(net, packed, packed_bwd, nullptr, nullptr, (n + 31) / 32, 32, d_out, stash, work, work_bytes, grads, 0, (hipStream_t)st,
+                             x, n);
 }
 
 int mi_nerf_image_metrics(const float* pred, const float* target, int64_t n, float* out2, void* scratch, size_t scratch_bytes, void* st) {

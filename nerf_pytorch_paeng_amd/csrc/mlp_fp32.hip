@@ -311,8 +311,16 @@ void mlp_fp32_kernel(const MlpArgs a) {
             }
         } else {
             acc_init<NT / 2>(acc, side + a.o_bias_d, hh);
-            gemm_part<NT / 2, HN, NT / 2>(acc, h, aq, smem, ring, lane);
-            gemm_part<NT / 2, KDE, NT>(acc, de, aq, smem, ring, lane);
+            if constexpr (STASH) {
+                float* row = a.stash_f + out_idx * W + 4 * hh;
+                auto hook = [&](int kq, int t) __attribute__((always_inline)) {
+                    if (t == NT / 2 - 1) store_chunk(h, kq, row);
+                };
+                gemm_part<NT / 2, HN, NT / 2, AL>(acc, h, aq, smem, ring, lane, hook);
+            } else {
+                gemm_part<NT / 2, HN, NT / 2, AL>(acc, h, aq, smem, ring, lane);
+            }
+            gemm_part<NT / 2, KDE, NT, AL>(acc, de, aq, smem, ring, lane);
         }
         float h2[HN / 2];
         acc_to_b<NT / 2, true>(acc, h2);
@@ -482,6 +490,23 @@ int mlp_rays_fp32_stash(const mi_nerf_net* net, const void* packed_dev, const fl
     a.stash_h = stash_h; a.stash_f = stash_f; a.stash_g = stash_g; a.stash_rows = (long long)n_rays * S;
     a.mask_h = mask_h; a.mask_g = mask_g;
     return net->W == 256 ? launch<256, 0, true>(a, a.n_wtiles, st) : launch<128, 0, true>(a, a.n_wtiles, st);
+}
+
+// training forward over pre-embedded rows (model/NeRF.py:33-52 called directly with gradients enabled): flat 32-row tiles;
+// the stash and masks are laid out for ceil(n / 32) "rays" of 32 samples (train_layout(net, ceil(n/32), 32))
+int mlp_embedded_fp32_stash(const mi_nerf_net* net, const void* packed_dev, const float* x_dev, int64_t n, float* out_dev, float* stash_h,
+                            float* stash_f, float* stash_g, unsigned* mask_h, unsigned* mask_g, hipStream_t st) {
+    if (int rc = check_net(net)) return rc;
+    MN_CHECK_ARG(n >= 0, "bad n=%lld", (long long)n);
+    if (n == 0) return MI_NERF_OK;
+    MN_CHECK_ARG(packed_dev && x_dev && out_dev && stash_h && stash_f && stash_g && mask_h && mask_g, "NULL device pointer");
+    MlpArgs a{};
+    fill_common(a, net, packed_dev, true);
+    a.x = x_dev; a.out = out_dev; a.n_pts = n;
+    a.n_wtiles = (n + 31) / 32;
+    a.stash_h = stash_h; a.stash_f = stash_f; a.stash_g = stash_g; a.stash_rows = a.n_wtiles * 32;
+    a.mask_h = mask_h; a.mask_g = mask_g;
+    return net->W == 256 ? launch<256, 1, true>(a, a.n_wtiles, st) : launch<128, 1, true>(a, a.n_wtiles, st);
 }
 
 int mlp_embedded_fp32(const mi_nerf_net* net, const void* packed_dev, const float* x_dev, int64_t n, float* out_dev,

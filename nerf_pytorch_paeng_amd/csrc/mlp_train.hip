@@ -39,7 +39,8 @@ struct DgradArgs {
     float* delta_h;           // [D][P][W]   dL/d(pre-activation of trunk layer l)
     float* delta_f;           // [P][W]      dL/d(linear_feat output)
     float* delta_d;           // [P][W/2]    dL/d(pre-activation of linear_d)
-    long long P;
+    long long P;              // rows per layer in the delta / stash buffers (n_rays * S)
+    long long n_valid;        // rows that exist (== P for rays; the embedded-row mode pads its last tile)
     long long n_wtiles;       // n_rays * tpr: the forward's (ray, 32-sample chunk) tiles
     int S, tpr;
     int D;
@@ -104,8 +105,9 @@ void mlp_dgrad_kernel(const DgradArgs a) {
         if (!wave_active) wt = a.n_wtiles - 1;
         const long long ray = wt / a.tpr;
         const int sample = (int)(wt - ray * a.tpr) * 32 + col;
-        const bool valid = wave_active && sample < a.S;
-        const long long idx = ray * a.S + (sample < a.S ? sample : a.S - 1);
+        long long idx = ray * a.S + (sample < a.S ? sample : a.S - 1);
+        const bool valid = wave_active && sample < a.S && idx < a.n_valid;
+        if (idx >= a.n_valid) idx = a.n_valid - 1;                 // padded rows recompute the last one
         // padding lanes (sample >= S) and inactive tail waves recompute a valid point: their row stores rewrite the same bytes
         const f32x4 dr = *(const f32x4*)(a.d_raw + idx * 4);
         const u32x2 mgv = *(const u32x2*)(a.mask_g + (wt * 64 + lane) * 2);
@@ -680,18 +682,22 @@ static int launch_dgrad(const DgradArgs& a, hipStream_t st) {
 // d_raw [P,4] -> flat parameter gradient (ParamOffsets order).  stash: written by mlp_rays_fp32_stash for the same
 // rays/z; work: scratch of train_layout().work_bytes.  stage 0: everything; 1: stop after the backward-data kernel
 // (deltas stay in `work` for inspection).
+// x_dev != NULL: the embedded-row mode (the forward was mlp_embedded_fp32_stash over n_rows rows): rays / z are unused, the
+// layer inputs gamma(x), gamma(d) are the caller's rows, and (n_rays, S) must be (ceil(n_rows / 32), 32).
 int mlp_backward_fp32(const mi_nerf_net* net, const void* packed_fwd, const void* packed_bwd, const float* rays, const float* z,
                       int64_t n_rays, int S, const float* d_raw, const void* stash, void* work, size_t work_bytes, float* grads,
-                      int stage, hipStream_t st) {
+                      int stage, hipStream_t st, const float* x_dev, int64_t n_rows) {
     MN_CHECK_ARG(net != nullptr, "net is NULL");
     MN_CHECK_ARG(net->L_x == 10 && net->L_d == 4, "unsupported encoding L_x=%d L_d=%d", net->L_x, net->L_d);
     MN_CHECK_ARG(net->skip >= -1, "bad skip=%d", net->skip);
     MN_CHECK_ARG(n_rays >= 0 && S >= 1, "bad sizes n_rays=%lld S=%d", (long long)n_rays, S);
-    const long long P = (long long)n_rays * S;
+    const long long Ppad = (long long)n_rays * S;                  // rows per layer in the stash / delta buffers
+    const long long P = x_dev ? n_rows : Ppad;                     // rows that exist
+    MN_CHECK_ARG(!x_dev || (S == 32 && n_rows >= 0 && n_rays == (n_rows + 31) / 32), "embedded mode wants (n_rays, S) = (ceil(n / 32), 32)");
     mi_nerf_train_layout L;
     if (int rc = train_layout(net, n_rays, S, &L)) return rc;
     if (P == 0) return MI_NERF_OK;
-    MN_CHECK_ARG(packed_fwd && packed_bwd && rays && z && d_raw && stash && work && grads, "NULL device pointer");
+    MN_CHECK_ARG(packed_fwd && packed_bwd && (x_dev || (rays && z)) && d_raw && stash && work && grads, "NULL device pointer");
     MN_CHECK_ARG(work_bytes >= L.work_bytes, "workspace too small: %zu < %zu", work_bytes, L.work_bytes);
     const int D = net->D, W = net->W;
     const int in_x = 3 + 6 * net->L_x, in_d = 3 + 6 * net->L_d, in_all = in_x + in_d;
@@ -716,13 +722,17 @@ int mlp_backward_fp32(const mi_nerf_net* net, const void* packed_fwd, const void
     a.mask_g = (const unsigned*)((const char*)stash + L.mask_g);
     a.delta_h = delta_h; a.delta_f = delta_f; a.delta_d = delta_d;
     a.S = S; a.tpr = (S + 31) / 32;
-    a.P = P; a.n_wtiles = (long long)n_rays * a.tpr; a.D = D;
+    a.P = Ppad; a.n_valid = P; a.n_wtiles = (long long)n_rays * a.tpr; a.D = D;
     if (int rc = (W == 256 ? launch_dgrad<256>(a, st) : launch_dgrad<128>(a, st))) return rc;
     if (stage == 1) return MI_NERF_OK;
 
-    // layer inputs gamma(x), gamma(d) as rows (nerf_process.py:69-85)
-    if (int rc = stage_embed(rays, z, n_rays, S, net->L_x, net->L_d, emb, st)) return rc;
-    const size_t PW = (size_t)P * W;
+    // layer inputs gamma(x), gamma(d) as rows (nerf_process.py:69-85), or the caller's own rows
+    const float* embc = x_dev;
+    if (!x_dev) {
+        if (int rc = stage_embed(rays, z, n_rays, S, net->L_x, net->L_d, emb, st)) return rc;
+        embc = emb;
+    }
+    const size_t PW = (size_t)Ppad * W;
     // wide products (both sides W or W/2 wide) in one launch: trunk layers 1..D-1 (activation part), linear_feat, linear_d (feature part)
     const float* h_last = stash_h + (size_t)(D - 1) * PW;
     {
@@ -745,12 +755,12 @@ int mlp_backward_fp32(const mi_nerf_net* net, const void* packed_fwd, const void
         if (int rc = flush()) return rc;
     }
     // products with a narrow side: gamma(x) into layer 0 and the skip layer, gamma(d) into linear_d, the density and colour heads
-    if (int rc = run_wgrad(delta_h, W, W, emb, in_all, in_x, P, grads + po.w_x[0], in_x, grads + po.b_x[0], partial, st)) return rc;
+    if (int rc = run_wgrad(delta_h, W, W, embc, in_all, in_x, P, grads + po.w_x[0], in_x, grads + po.b_x[0], partial, st)) return rc;
     for (int l = 1; l < D; ++l)
         if (po.in_l[l] != W)
-            if (int rc = run_wgrad(delta_h + (size_t)l * PW, W, W, emb, in_all, in_x, P, grads + po.w_x[l], po.in_l[l], nullptr, partial, st)) return rc;
+            if (int rc = run_wgrad(delta_h + (size_t)l * PW, W, W, embc, in_all, in_x, P, grads + po.w_x[l], po.in_l[l], nullptr, partial, st)) return rc;
     if (int rc = run_wgrad(d_raw + 3, 4, 1, h_last, W, W, P, grads + po.w_dens, W, grads + po.b_dens, partial, st)) return rc;
-    if (int rc = run_wgrad(delta_d, W / 2, W / 2, emb + in_x, in_all, in_d, P, grads + po.w_d + W, W + in_d, nullptr, partial, st)) return rc;
+    if (int rc = run_wgrad(delta_d, W / 2, W / 2, embc + in_x, in_all, in_d, P, grads + po.w_d + W, W + in_d, nullptr, partial, st)) return rc;
     if (int rc = run_wgrad(d_raw, 4, 3, stash_g, W / 2, W / 2, P, grads + po.w_color, W / 2, grads + po.b_color, partial, st)) return rc;
     return MI_NERF_OK;
 }

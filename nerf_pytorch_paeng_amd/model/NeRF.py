@@ -3,9 +3,9 @@
 Same constructor arguments, same sub-module and parameter names (so ``load_state_dict`` accepts the
 reference's checkpoints, train.py:105-114), same ``forward(x, is_fine)`` contract.  The forward pass
 is the hand-written MFMA kernel (``mi_nerf_mlp_embedded``): parameters are packed into the kernel's
-streaming layout on first use and re-packed only when they change.  ``forward`` itself is inference only (its callers
-run under ``torch.no_grad()``, test.py:36,140); training goes through ``nerf_process.batchify_rays_and_render_by_chunk``
-with gradients enabled (train_path.py), which differentiates w.r.t. this module's parameters.
+streaming layout on first use and re-packed only when they change.  Under ``torch.no_grad()`` (test.py:36,140) ``forward`` is
+the inference kernel; with gradients enabled it is differentiable w.r.t. the selected network's parameters (hand-written
+backward, train_path.py), so a caller that keeps the reference's own ``nerf_process.py`` and swaps only the model still trains.
 """
 from __future__ import annotations
 
@@ -55,10 +55,15 @@ class NeRF(nn.Module):
         """x [n, input_ch + input_ch_d] -> [n, 4] = cat([rgb_raw, density_raw]) (NeRF.py:51,70-78)."""
         from ..weights import packed_for
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            # never hand back a tensor that silently carries no graph: the differentiable entry is the render path
-            raise MiNerfError("NeRF.forward(x, is_fine) is the inference kernel and records no autograd graph: call it under "
-                              "torch.no_grad() (test.py:36), or train through nerf_process.batchify_rays_and_render_by_chunk / "
-                              "render_rays with gradients enabled (train.py:53)")
+            # the reference's own render_rays calls model(embedded, is_fine) with gradients enabled (nerf_process.py:190-192,
+            # 206-207): differentiable w.r.t. the selected network's parameters (nothing flows into x)
+            from .. import train_path
+            st = train_path._state_for(self)
+            x = as_f32_dev(x, st.device)
+            lead = x.shape[:-1]
+            params = st.params(self.model_fine if is_fine else self.model_coarse)
+            out = train_path._EmbeddedTrain.apply(st, x.reshape(-1, x.shape[-1]).contiguous(), *params)
+            return out.reshape(*lead, 4)
         packed = packed_for(self)
         x = as_f32_dev(x, packed.device)
         lead = x.shape[:-1]

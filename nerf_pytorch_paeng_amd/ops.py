@@ -348,6 +348,37 @@ def mlp_backward(net: Net, packed: torch.Tensor, packed_bwd: torch.Tensor, rays:
     return grads, work
 
 
+def mlp_embedded_train(net: Net, packed: torch.Tensor, x: torch.Tensor):
+    """Training forward over pre-embedded rows [n, in_x + in_d]: (out [n,4], stash)."""
+    n = x.shape[0]
+    if x.dim() != 2 or x.shape[1] != 6 + 6 * net.L_x + 6 * net.L_d:
+        raise MiNerfError(f"x must be [n, {6 + 6 * net.L_x + 6 * net.L_d}], got {tuple(x.shape)}")
+    lay = train_layout(net, (n + 31) // 32, 32)
+    stash = torch.empty(lay.stash_bytes, dtype=torch.uint8, device=x.device)
+    out = torch.empty(n, 4, dtype=torch.float32, device=x.device)
+    with _guard(x.device):
+        check(lib().mi_nerf_mlp_embedded_train(C.byref(net), dev_ptr(packed, "packed", torch.uint8, 16), dev_ptr(x, "x"), n, dev_ptr(out, "out", align=16),
+                                               dev_ptr(stash, "stash", torch.uint8, 16), stash.numel(), stream_ptr(x.device)), "mi_nerf_mlp_embedded_train")
+    return out, stash
+
+
+def mlp_embedded_backward(net: Net, packed: torch.Tensor, packed_bwd: torch.Tensor, x: torch.Tensor, d_out: torch.Tensor, stash: torch.Tensor) -> torch.Tensor:
+    """d_out [n,4] -> flat parameter gradient (param_names order) for the embedded-row forward."""
+    n = x.shape[0]
+    if tuple(d_out.shape) != (n, 4):
+        raise MiNerfError(f"d_out must be {(n, 4)}, got {tuple(d_out.shape)}")
+    lay = train_layout(net, (n + 31) // 32, 32)
+    dev = x.device
+    work = torch.empty(lay.work_bytes, dtype=torch.uint8, device=dev)
+    grads = torch.zeros(param_count(net), dtype=torch.float32, device=dev)
+    with _guard(dev):
+        check(lib().mi_nerf_mlp_embedded_backward(C.byref(net), dev_ptr(packed, "packed", torch.uint8, 16), dev_ptr(packed_bwd, "packed_bwd", torch.uint8, 16),
+                                                  dev_ptr(x, "x"), n, dev_ptr(d_out, "d_out", align=16), dev_ptr(stash, "stash", torch.uint8, 16),
+                                                  dev_ptr(work, "work", torch.uint8, 16), work.numel(), dev_ptr(grads, "grads"), stream_ptr(dev)),
+              "mi_nerf_mlp_embedded_backward")
+    return grads
+
+
 def wgrad_product(delta: torch.Tensor, M: int, x: torch.Tensor, N: int, P: int, want_bias: bool = True, iters: int = 1, timed: bool = False):
     """out[M,N] = delta[:P,:M]^T x[:P,:N] (+ bias[M] = column sums of delta) with the backward pass's own kernels.
     ``delta`` / ``x`` are 2-D row-major with at least P rows (wide operands: 60 rows of slack past P).  Returns

@@ -127,6 +127,35 @@ class _RenderTrain(torch.autograd.Function):
         return (None, None, None, None, None, None, *gc, *gf)
 
 
+class _EmbeddedTrain(torch.autograd.Function):
+    """model(embedded, is_fine) with gradients: pre-embedded rows [n, 90] and ONE network's parameters -> [n, 4]."""
+
+    @staticmethod
+    def forward(ctx, st: _TrainState, x, *params):
+        flat = _flat(params)
+        blob = ops.pack_apply(st.map_fwd, flat)
+        out, stash = ops.mlp_embedded_train(st.net, blob, x)
+        ctx.st = st
+        ctx.save_for_backward(x, flat, blob, stash)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        st: _TrainState = ctx.st
+        x, flat, blob, stash = ctx.saved_tensors
+        blob_b = ops.pack_apply(st.map_bwd, flat)
+        grads = ops.mlp_embedded_backward(st.net, blob, blob_b, x, g_out.contiguous().float(), stash)
+        out, off = [], 0
+        for k in st.names:
+            shape = _param_shape(st.net, k)
+            cnt = 1
+            for sdim in shape:
+                cnt *= sdim
+            out.append(grads[off:off + cnt].view(shape))
+            off += cnt
+        return (None, None, *out)
+
+
 def _param_shape(net: Net, key: str) -> Tuple[int, ...]:
     W, in_x, in_d = net.W, 3 + 6 * net.L_x, 3 + 6 * net.L_d
     mod, kind = key.rsplit(".", 1)
