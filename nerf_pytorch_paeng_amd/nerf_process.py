@@ -146,8 +146,7 @@ raw2outputs = post_process          # north-star alias (original NeRF naming)
 def run_network(model, embedded, is_fine: bool = False):
     """north-star alias: the chunked ``model(embedded)`` loop of nerf_process.py:190-192,206-207 as one launch."""
     if train_path.wants_grad(model):
-        raise MiNerfError("run_network is the inference kernel and records no autograd graph: call it under torch.no_grad(), "
-                          "or train through batchify_rays_and_render_by_chunk / render_rays with gradients enabled")
+        return model(embedded, is_fine)                          # differentiable route of the model mirror (model/NeRF.py)
     packed = packed_for(model)
     return ops.mlp_embedded(packed.net, packed.blob(is_fine), as_f32_dev(embedded, packed.device))
 
