@@ -1,20 +1,25 @@
 #!/usr/bin/env python3
 """Benchmark of the NeRF volume-rendering hot path on MI355X (driver contract: one JSON line on rank 0).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          # N > 1: this process only LAUNCHES N workers (one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W             # or let torchrun start the workers
 
 Metric (BASELINE.json): rays/sec on a 4096-ray batch with 64 coarse + 128 fine samples through the 8x256
 coarse/fine MLPs, fp32 -- BASELINE config #2, "lego coarse+fine 4096 rays, 64+128 samples, 8x256 MLP,
 1xMI355X fp32".  One step = one full render_rays pass (stratified sampling -> coarse MLP -> composite ->
-inverse-CDF resampling + merge -> fine MLP over all 192 depths -> composite) over one 4096-ray batch whose
-rays are resident in HBM.  With N GPUs every rank renders its own 4096-ray batch (weak scaling: rays are
-independent, no data-path collective); value = N * 4096 * K / max-over-ranks time.
+inverse-CDF resampling + merge -> fine MLP over all 192 depths -> composite) over one batch whose rays are
+resident in HBM.
 
-Also reported on the same line: the 800x800 frame time (rows sharded over the ranks, one RCCL all-gather of
-the output tiles), `roofline` for the dominant kernel (the fine-network fused MLP launch, hipEvent-timed on
-its launch stream) and `cpu_baseline` (the CPU oracle timed on the host cores; rank 0, N=1 only).
+Scaling: the 4096-ray batch is SHARDED over the N GPUs -- 4096/N contiguous rays per rank
+(512 at N = 8), no data-path collective -- so `value` = 4096 * K / max-over-ranks time is STRONG scaled.
+`value_weak` (every rank renders its own 4096-ray batch, N * 4096 * K / time) is measured in a second leg of
+the same run for N > 1; at N = 1 the two are the same measurement.
+
+Also on the line: the 800x800 frame time (rows sharded over the ranks, ONE all-gather of the output tiles
+over RCCL), `roofline` for the dominant kernel (the fine-network fused MLP launch, hipEvent-timed on its
+launch stream), `small_batch` (the same step at 256..2048 rays on one GPU: what a rank sees under strong
+scaling) and `cpu_baseline` (the CPU oracle timed on the host cores; rank 0, N = 1 only).
 
 Synthetic inputs: lego camera geometry, pose_spherical(0,-30,4), 4096 pixels from
 RandomState(0), Xavier(seed 0) weights with the density head x20, counter-based jitter seed 0.
@@ -22,14 +27,14 @@ RandomState(0), Xavier(seed 0) weights with the density head x20, counter-based 
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from types import SimpleNamespace
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -41,6 +46,8 @@ N_RAYS, SC, NF = 4096, 64, 128
 POINTS_PER_RAY = SC + (SC + NF)          # 64 coarse + 192 fine network evaluations
 FLOP_PER_RAY = FLOP_PER_POINT * POINTS_PER_RAY          # 303,824,896
 PEAK_F32_MFMA_TFLOPS = 157.3             # MI355X_MICROARCH.md: 256 CU x 256 FLOP/clk x 2.4 GHz
+PEAK_BF16_MFMA_TFLOPS = 2500.0           # dense bf16 MFMA peak (the headline 5 PF figure includes 2:1 sparsity)
+KERNEL_SOURCES = ("mlp_fp32.hip", "mlp_core.h", "layout.h", "common.h")
 
 
 def parse():
@@ -50,21 +57,74 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames", type=int, default=2, help="timed 800x800 frames (0 disables the frame metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--train-steps", type=int, default=8,
-                    help="timed training steps (forward + hand-written backward + Adam, train.py:53-70) reported as `train`; 0 disables")
+    ap.add_argument("--train-steps", type=int, default=None,
+                    help="timed training steps (forward + hand-written backward + Adam, train.py:53-70) reported as `train`; "
+                         "default 8 on one GPU, 0 on several")
     ap.add_argument("--bf16", action="store_true", help="bf16 MFMA variant (BASELINE config #5)")
     ap.add_argument("--workload", choices=["lego", "fern"], default="lego",
                     help="lego: BASELINE config #2 (default, the headline metric); fern: config #4, LLFF geometry + NDC rays")
+    ap.add_argument("--scaling", choices=["strong", "weak", "both"], default="both",
+                    help="strong: the 4096-ray batch sharded over the GPUs (value); weak: 4096 rays per GPU (value_weak); both (default)")
+    ap.add_argument("--no-small-batch", action="store_true", help="skip the 256..2048-ray legs (N = 1)")
     return ap.parse_args()
 
 
-def main():
-    args = parse()
+# ----------------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` without a torchrun environment.  This process makes NO GPU call (it does
+# not even import torch); it starts one worker per GPU as a child process and waits for them.
+# ----------------------------------------------------------------------------------------------------------
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_workers(n: int) -> int:
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env))
+    rc = 0
+    alive = set(range(n))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                sys.stderr.write(f"bench.py: worker rank {r} exited with status {code}; stopping the others\n")
+                for o in alive:
+                    procs[o].terminate()          # exact children of this process, by PID
+        if alive:
+            time.sleep(0.05)
+    return rc
+
+
+def kernel_build_id() -> str:
+    """sha256 (first 16 hex digits) of the fused-MLP kernel's sources: ties a committed PMC figure to a build."""
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "nerf_pytorch_paeng_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def worker(args) -> None:
+    import numpy as np
+    import torch
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     import torch.distributed as dist
@@ -72,7 +132,7 @@ def main():
     backend = os.environ.get("BENCH_BACKEND", "nccl")
     ndev = torch.cuda.device_count()
     if world > ndev and backend == "nccl":
-        raise SystemExit(f"{world} ranks but {ndev} GPU(s): RCCL needs one GPU per rank")
+        raise SystemExit(f"{world} ranks but {ndev} GPU(s): RCCL needs one GPU per rank (BENCH_BACKEND=gloo rehearses the plumbing)")
     dev = torch.device("cuda", local_rank % ndev)
     torch.cuda.set_device(dev)
     if world > 1:
@@ -91,73 +151,122 @@ def main():
         if world > 1:
             dist.barrier()
 
+    def max_over_ranks(t: float) -> float:
+        if world == 1:
+            return t
+        tm = torch.tensor([t], dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        return float(tm.item())
+
+    train_steps = args.train_steps if args.train_steps is not None else (8 if world == 1 else 0)
+
     # ---- inputs (resident in HBM before any timed region) ----------------------------------------------
     sd = synthetic.make_state_dict(0, 8, 256)
     packed = weights.PackedNeRF.from_state_dict(sd, dev)
     fern = args.workload == "fern"
     K, H, W = synthetic.fern_camera() if fern else synthetic.lego_camera()
     pose = synthetic.fern_pose() if fern else synthetic.pose_spherical(0.0, -30.0, 4.0)
-    pix_all = synthetic.pixel_batch(H, W, N_RAYS * world, 0)                # each rank gets its own 4096 pixels
-    pix = torch.from_numpy(pix_all[rank * N_RAYS:(rank + 1) * N_RAYS]).to(dev)
-    o, d = ops.make_o_d_pixels(W, H, K, pose, pix)
-    if fern:                                                                # NDC warp, near plane 1 (nerf_process.py:224-226)
-        o, d = ops.ndc_rays(H, W, float(K[0][0]), 1.0, o, d)
-    rays = torch.cat([o, d], -1).contiguous()
     opts = SimpleNamespace(near=0.0 if fern else 2.0, far=1.0 if fern else 6.0, N_samples_c=SC, N_samples_f=NF, perturb=1.0,
                            chunk_rays=N_RAYS, chunk_pts=524288, data_type="llff" if fern else "blender",
                            gpu_ids=list(range(world)), rank=rank)
     cfg = ops.render_cfg(opts.near, opts.far, SC, NF, False, args.bf16)
-    t_rand = ops.fill_uniform(0, 0, rank * N_RAYS, N_RAYS, SC, dev)
-    u = ops.fill_uniform(0, 1, rank * N_RAYS, N_RAYS, NF, dev)
     blobs = packed.bf16() if args.bf16 else (packed.coarse, packed.fine)
-    out_bufs = (torch.empty(N_RAYS, 3, device=dev), torch.empty(N_RAYS, device=dev),
-                torch.empty(N_RAYS, 3, device=dev), torch.empty(N_RAYS, device=dev))
-    ws = torch.empty(ops.workspace_layout(cfg, N_RAYS).total, dtype=torch.uint8, device=dev)
+    pix_all = synthetic.pixel_batch(H, W, N_RAYS * world, 0)
 
-    def step():
-        ops.render_rays(packed.net, blobs[0], blobs[1], cfg, rays, t_rand, u, workspace=ws, out=out_bufs)
+    def make_batch(first: int, n: int):
+        """Rays [first, first+n) of the synthetic pixel list, their jitter (keyed on the GLOBAL ray index) and buffers."""
+        pix = torch.from_numpy(pix_all[first:first + n]).to(dev)
+        o, d = ops.make_o_d_pixels(W, H, K, pose, pix)
+        if fern:                                                            # NDC warp, near plane 1 (nerf_process.py:224-226)
+            o, d = ops.ndc_rays(H, W, float(K[0][0]), 1.0, o, d)
+        b = SimpleNamespace(n=n, o=o, d=d, rays=torch.cat([o, d], -1).contiguous(),
+                            t_rand=ops.fill_uniform(0, 0, first, n, SC, dev), u=ops.fill_uniform(0, 1, first, n, NF, dev),
+                            out=(torch.empty(n, 3, device=dev), torch.empty(n, device=dev), torch.empty(n, 3, device=dev), torch.empty(n, device=dev)),
+                            ws=torch.empty(ops.workspace_layout(cfg, n).total, dtype=torch.uint8, device=dev))
+        return b
+
+    def step(b):
+        ops.render_rays(packed.net, blobs[0], blobs[1], cfg, b.rays, b.t_rand, b.u, workspace=b.ws, out=b.out)
+
+    def timed_steps(b, warmup: int, steps: int) -> float:
+        """W untimed + EXACTLY K timed steps, barrier + synchronize on both sides, max over ranks (seconds)."""
+        for _ in range(warmup):
+            step(b)
+        torch.cuda.synchronize(dev)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(b)
+        torch.cuda.synchronize(dev)
+        barrier()
+        return max_over_ranks(time.perf_counter() - t0)
 
     # ---- rays/sec on the 4096-ray batch ------------------------------------------------------------------
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize(dev)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize(dev)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-    rays_per_s = world * N_RAYS * args.steps / elapsed
-    ms_per_step = 1e3 * elapsed / args.steps
-    assert torch.isfinite(out_bufs[2]).all()
+    first_s, n_s = mdist.shard_range(N_RAYS, world, rank)            # strong: this rank's contiguous slice of THE batch
+    strong = make_batch(first_s, n_s)
+    weak = strong if world == 1 else make_batch(rank * N_RAYS, N_RAYS)
+    value = value_weak = ms_strong = ms_weak = None
+    if args.scaling in ("strong", "both") or world == 1:
+        el = timed_steps(strong, args.warmup, args.steps)
+        value, ms_strong = N_RAYS * args.steps / el, 1e3 * el / args.steps
+        assert torch.isfinite(strong.out[2]).all()
+    if world == 1:
+        value_weak, ms_weak = value, ms_strong
+    elif args.scaling in ("weak", "both"):
+        el = timed_steps(weak, args.warmup, args.steps)
+        value_weak, ms_weak = world * N_RAYS * args.steps / el, 1e3 * el / args.steps
+        assert torch.isfinite(weak.out[2]).all()
+    headline_strong = value is not None
+    main = strong if headline_strong else weak
 
-    # ---- roofline of the dominant kernel: the fine-network fused MLP launch ---------------------------------
-    views = ops.workspace_views(cfg, N_RAYS, ws)
+    # ---- roofline of the dominant kernel: the fine-network fused MLP launch of the timed step ------------------
+    views = ops.workspace_views(cfg, main.n, main.ws)
     z_f = views["z_f"].clone()
-    raw_f = torch.empty(N_RAYS, SC + NF, 4, device=dev)
+    raw_f = torch.empty(main.n, SC + NF, 4, device=dev)
     iters = max(5, min(args.steps, 50))
-    ops.time_mlp_rays(packed.net, blobs[1], rays, z_f, raw_f, 2, args.bf16)
-    k_ms = ops.time_mlp_rays(packed.net, blobs[1], rays, z_f, raw_f, iters, args.bf16)
-    k_flop = N_RAYS * (SC + NF) * FLOP_PER_POINT                             # algorithmic FLOP per launch
+    ops.time_mlp_rays(packed.net, blobs[1], main.rays, z_f, raw_f, 2, args.bf16)
+    k_ms = ops.time_mlp_rays(packed.net, blobs[1], main.rays, z_f, raw_f, iters, args.bf16)
+    k_flop = main.n * (SC + NF) * FLOP_PER_POINT                             # algorithmic FLOP per launch
     achieved = k_flop / (k_ms * 1e-3) / 1e12
-    traffic = None                     # HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/README.md)
+    # HBM bytes per launch come from separate rocprofv3 --pmc passes (profiles/README.md): a committed figure, tied to the
+    # kernel build it was measured on.  It is reported only for the launch shape it was measured at.
+    traffic = traffic_build = None
+    build_id = kernel_build_id()
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            traffic = None if args.bf16 else json.load(f)["hbm_bytes_per_launch"]
+            tj = json.load(f)
+        if not args.bf16 and main.n == N_RAYS and not fern:
+            traffic, traffic_build = tj["hbm_bytes_per_launch"], tj.get("kernel_build")
     except (OSError, KeyError, ValueError):
         pass
-    roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-                "kernel": "mlp_fp32_kernel<256,0,10,4> (fine net, 786432 points/launch)", "kernel_ms": round(k_ms, 4),
-                "flop_per_launch": k_flop}
+    peak = PEAK_BF16_MFMA_TFLOPS if args.bf16 else PEAK_F32_MFMA_TFLOPS
+    roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(achieved / peak, 4), "traffic": traffic,
+                "kernel": ("mlp_bf16_kernel" if args.bf16 else "mlp_fp32_kernel<256,0,10,4>") + f" (fine net, {main.n * (SC + NF)} points/launch)",
+                "kernel_ms": round(k_ms, 4), "flop_per_launch": k_flop, "kernel_build": build_id,
+                "traffic_measured_on_build": traffic_build, "traffic_is_current": (traffic_build == build_id) if traffic is not None else None}
     if args.bf16:
-        roofline["kernel"] = "mlp_bf16_kernel (fine net, 786432 points/launch)"
-        roofline["frac_of_bf16_peak"] = round(achieved / 2500.0, 4)
+        roofline["peak_is"] = "dense bf16 MFMA"
+        roofline["frac_of_f32_mfma_peak"] = round(achieved / PEAK_F32_MFMA_TFLOPS, 4)
+
+    # ---- the same step at small batches (one GPU): what a rank runs under strong scaling ---------------------------
+    small = None
+    if world == 1 and not args.no_small_batch:
+        small = []
+        for n in (256, 512, 1024, 2048):
+            b = make_batch(0, n)
+            reps = max(args.steps, 20)
+            el = timed_steps(b, 3, reps)
+            zf = ops.workspace_views(cfg, n, b.ws)["z_f"].clone()
+            rf = torch.empty(n, SC + NF, 4, device=dev)
+            ops.time_mlp_rays(packed.net, blobs[1], b.rays, zf, rf, 2, args.bf16)
+            kms = ops.time_mlp_rays(packed.net, blobs[1], b.rays, zf, rf, 20, args.bf16)
+            rps = n * reps / el
+            small.append({"rays": n, "ms_per_step": round(1e3 * el / reps, 4), "rays_per_s": round(rps, 1),
+                          "frac_of_roofline_end_to_end": round(rps * FLOP_PER_RAY / 1e12 / peak, 4),
+                          "fine_kernel_ms": round(kms, 4),
+                          "fine_kernel_frac": round(n * (SC + NF) * FLOP_PER_POINT / (kms * 1e-3) / 1e12 / peak, 4)})
+            del b, zf, rf
 
     # ---- 800x800 frame, rows sharded over the ranks, one all-gather of the tiles ----------------------------
     frame_ms = None
@@ -171,17 +280,12 @@ def main():
             rgb, disp = mdist.render_frame(H, W, K, fpose, packed, opts, seed=0, bf16=args.bf16)
         torch.cuda.synchronize(dev)
         barrier()
-        ft = time.perf_counter() - t0
-        if world > 1:
-            tmax = torch.tensor([ft], dtype=torch.float64, device=coll_dev)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            ft = float(tmax.item())
-        frame_ms = 1e3 * ft / args.frames
+        frame_ms = 1e3 * max_over_ranks(time.perf_counter() - t0) / args.frames
         assert rgb.shape == (H, W, 3) and torch.isfinite(rgb).all()
 
     # ---- training step: forward + backward + Adam on this rank's 4096-ray batch --------------
     train = None
-    if args.train_steps > 0 and not args.bf16:
+    if train_steps > 0 and not args.bf16:
         from nerf_pytorch_paeng_amd.model import NeRF, get_positional_encoder
         model = NeRF(8, 256, 63, 27).to(dev)
         model.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
@@ -191,7 +295,7 @@ def main():
         NP.manual_seed(0)
 
         def train_step():
-            rgb_c, _, rgb_f, _ = NP.batchify_rays_and_render_by_chunk(o, d, model, posenc, H, W, K, opts, ray_offset=rank * N_RAYS)
+            rgb_c, _, rgb_f, _ = NP.batchify_rays_and_render_by_chunk(weak.o, weak.d, model, posenc, H, W, K, opts, ray_offset=rank * N_RAYS)
             optim.zero_grad()
             loss = torch.nn.functional.mse_loss(rgb_c, target) + torch.nn.functional.mse_loss(rgb_f, target)   # train.py:60-66
             loss.backward()
@@ -203,20 +307,17 @@ def main():
         torch.cuda.synchronize(dev)
         barrier()
         t0 = time.perf_counter()
-        for _ in range(args.train_steps):
+        for _ in range(train_steps):
             loss = train_step()
         torch.cuda.synchronize(dev)
         barrier()
-        tt = time.perf_counter() - t0
-        if world > 1:
-            tmax = torch.tensor([tt], dtype=torch.float64, device=coll_dev)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            tt = float(tmax.item())
+        tt = max_over_ranks(time.perf_counter() - t0)
         assert torch.isfinite(loss).all()
-        t_ms = 1e3 * tt / args.train_steps
+        t_ms = 1e3 * tt / train_steps
         train_flop_per_ray = 2 * (593408 + 557696 + 593408) * POINTS_PER_RAY            # forward + backward-data + backward-weights
-        train = {"ms_per_step": round(t_ms, 3), "rays_per_s": round(world * N_RAYS / (t_ms * 1e-3), 1), "steps": args.train_steps,
+        train = {"ms_per_step": round(t_ms, 3), "rays_per_s": round(world * N_RAYS / (t_ms * 1e-3), 1), "steps": train_steps,
                  "frac_of_f32_mfma_roofline": round(N_RAYS / (t_ms * 1e-3) * train_flop_per_ray / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                 "peak_mem_GiB": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
                  "what": "batchify_rays_and_render_by_chunk (grad) + MSE(rgb_c)+MSE(rgb_f) + loss.backward() + Adam.step(), "
                          f"{N_RAYS} rays per GPU, each rank an independent replica (the reference has no data-parallel training)"}
         # roofline leg of the training kernels' GEMM: one 256x256 weight-gradient product over the fine net's 786 432 points
@@ -232,7 +333,7 @@ def main():
 
     # ---- global-batch staging: rays for 100 800x800 training images + epoch shuffle, on the device ----
     staging = None
-    if rank == 0 and not args.bf16 and not fern and args.train_steps > 0:
+    if rank == 0 and world == 1 and not args.bf16 and not fern and train_steps > 0:
         from nerf_pytorch_paeng_amd import harness
         n_img = 100
         imgs = torch.rand(n_img, H, W, 3, device=dev)
@@ -265,7 +366,7 @@ def main():
         # the GPU box gives one GPU's job a 16-core share of a many-core host: do not oversubscribe
         n_thr = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
         torch.set_num_threads(n_thr)
-        rc, tc, uc = rays.cpu(), t_rand.cpu(), u.cpu()
+        rc, tc, uc = main.rays.cpu(), main.t_rand.cpu(), main.u.cpu()
         pcfg = R.PathConfig()
         with torch.no_grad():
             R.render_rays(rc[:256], sd, pcfg, tc[:256], uc[:256])                            # warm-up
@@ -287,25 +388,36 @@ def main():
             train_cpu = round(n_tr / (time.perf_counter() - t0), 1)
         cpu = {"value": round(n_cpu / float(np.median(reps)), 1), "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
                "train_rays_per_s": train_cpu,
-               "sample": f"oracle/restate.py render_rays (torch CPU fp32) on the first {n_cpu} rays of the same 4096-ray batch, "
-                         f"median of {len(reps)} reps"}
+               "sample": f"oracle/restate.py render_rays (torch CPU fp32, {torch.get_num_threads()} threads: this job's share of the host) on the first "
+                         f"{n_cpu} rays of the same 4096-ray batch, median of {len(reps)} reps; SURVEY section 6 timed the reference itself at "
+                         "691 rays/s on 8 vCPU with its own 4096-ray chunks (larger GEMMs per call than this 1024-ray sample)"}
 
     if rank == 0:
+        head_value = value if headline_strong else value_weak
+        head_ms = ms_strong if headline_strong else ms_weak
+        per_gpu = n_s if headline_strong else N_RAYS
         line = {
             "metric": "rays/sec (4096-ray batch, 64c+128f samples) + 800x800 frame render ms",
-            "value": round(rays_per_s, 1), "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "value": round(head_value, 1), "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(head_ms, 4), "higher_is_better": True, "scaling": "strong" if headline_strong else "weak", "vs_baseline": None,
             "dtype": "bf16" if args.bf16 else "f32", "data": "synthetic",
-            "config": {"workload": ("fern LLFF NDC rays, coarse+fine 4096 rays per GPU, 64+128 samples, 8x256 MLP (BASELINE config #4)" if fern else
-                                    "lego coarse+fine 4096 rays per GPU, 64+128 samples, 8x256 MLP (BASELINE config #2)") +
+            "value_weak": None if value_weak is None else round(value_weak, 1),
+            "ms_per_step_weak": None if ms_weak is None else round(ms_weak, 4),
+            "config": {"workload": ("fern LLFF NDC rays, coarse+fine 4096-ray batch, 64+128 samples, 8x256 MLP (BASELINE config #4)" if fern else
+                                    "lego coarse+fine 4096-ray batch, 64+128 samples, 8x256 MLP (BASELINE config #2)") +
                                    (" -- bf16 MFMA variant (config #5)" if args.bf16 else ""),
-                       "rays_per_gpu": N_RAYS, "samples": [SC, NF], "net": "8x256, skip 4, L_x 10, L_d 4",
-                       "parallelism": f"rays sharded over {world} GPU(s), no data-path collective"},
+                       "rays_per_gpu": per_gpu, "rays_per_gpu_weak": N_RAYS, "samples": [SC, NF], "net": "8x256, skip 4, L_x 10, L_d 4",
+                       "parallelism": (f"the 4096-ray batch split into {world} contiguous slices of {per_gpu} rays, one per GPU, no data-path collective "
+                                       f"(value); value_weak: {N_RAYS} rays on each of {world} GPU(s); frame: rows over {world} GPU(s) + one all-gather")},
             "frame_ms_800x800": None if (frame_ms is None or fern) else round(frame_ms, 2),
             "frame_ms": None if frame_ms is None else round(frame_ms, 2), "frame_hw": [H, W],
-            "frac_of_f32_mfma_roofline_end_to_end": round(rays_per_s / world * FLOP_PER_RAY / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+            "frac_of_roofline_end_to_end": round(head_value / world * FLOP_PER_RAY / 1e12 / peak, 4),
             "roofline": roofline,
         }
+        if not args.bf16:
+            line["frac_of_f32_mfma_roofline_end_to_end"] = line["frac_of_roofline_end_to_end"]
+        if small is not None:
+            line["small_batch"] = small
         if train is not None:
             line["train"] = train
         if staging is not None:
@@ -316,6 +428,15 @@ def main():
     if world > 1:
         barrier()                      # rank 0 may still be printing / staging: tear the group down together
         dist.destroy_process_group()
+
+
+def main():
+    args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_workers(args.gpus))             # before anything in this process touches the GPU
+    worker(args)
 
 
 if __name__ == "__main__":

@@ -13,6 +13,10 @@
   pixels only.
 * ``get_render_pose`` / ``pose_spherical`` -- the 360-degree camera path (dataset/render_pose.py:28-43), built on the
   host once and uploaded once.
+* ``normalize`` / ``viewmatrix`` / ``poses_avg`` / ``render_path_spiral`` / ``recenter_poses`` / ``llff_render_poses`` /
+  ``llff_cameras`` -- the forward-facing (LLFF) camera path (dataset/load_llff.py:151-204, 277-346): the spiral the
+  reference's loader hands to ``render()`` for ``data_type == 'llff'`` (main.py:43, test.py:125-145).  Host float64
+  numpy like the reference (120 poses of 15 numbers; one upload).
 
 PNG output uses a 30-line zlib encoder (imageio, which the reference uses, is not a dependency of this path).
 """
@@ -97,6 +101,96 @@ def get_render_pose(n_angle: int = 1, single_angle: float = -1, phi: float = -30
 
 
 # ---------------------------------------------------------------------------------------------------
+# LLFF (forward-facing) camera path: dataset/load_llff.py:151-204 and the spiral set-up of :277-346.
+# Poses are [N, 3, 5] camera-to-world matrices with the (H, W, focal) column of poses_bounds.npy appended.
+# ---------------------------------------------------------------------------------------------------
+def normalize(x):
+    """load_llff.py:151-152."""
+    return x / np.linalg.norm(x)
+
+
+def viewmatrix(z, up, pos):
+    """Camera frame looking along ``z`` with ``up`` as the approximate y axis (load_llff.py:155-161) -> [3, 4]."""
+    back = normalize(z)
+    right = normalize(np.cross(up, back))
+    true_up = normalize(np.cross(back, right))
+    return np.stack([right, true_up, back, pos], 1)
+
+
+def poses_avg(poses):
+    """Average camera of a rig (load_llff.py:169-176) -> [3, 5]: mean position, summed viewing / up directions, hwf of pose 0."""
+    hwf = poses[0, :3, -1:]
+    center = poses[:, :3, 3].mean(0)
+    back = normalize(poses[:, :3, 2].sum(0))
+    up = poses[:, :3, 1].sum(0)
+    return np.concatenate([viewmatrix(back, up, center), hwf], 1)
+
+
+def render_path_spiral(c2w, up, rads, focal, zdelta, zrate, rots, N):
+    """``N`` poses on a spiral around ``c2w`` looking at the point ``focal`` in front of it (load_llff.py:179-189).
+    ``zdelta`` is accepted and unused, as in the reference."""
+    rads = np.array(list(rads) + [1.])
+    hwf = c2w[:, 4:5]
+    out = []
+    for theta in np.linspace(0., 2. * np.pi * rots, int(N) + 1)[:-1]:
+        eye = np.dot(c2w[:3, :4], np.array([np.cos(theta), -np.sin(theta), -np.sin(theta * zrate), 1.]) * rads)
+        look = normalize(eye - np.dot(c2w[:3, :4], np.array([0, 0, -focal, 1.])))
+        out.append(np.concatenate([viewmatrix(look, up, eye), hwf], 1))
+    return out
+
+
+def recenter_poses(poses):
+    """Express every pose in the frame of the average camera (load_llff.py:192-204)."""
+    out = poses + 0
+    bottom = np.reshape([0, 0, 0, 1.], [1, 4])
+    c2w = np.concatenate([poses_avg(poses)[:3, :4], bottom], -2)
+    rows = np.tile(np.reshape(bottom, [1, 1, 4]), [poses.shape[0], 1, 1])
+    p44 = np.concatenate([poses[:, :3, :4], rows], -2)
+    p44 = np.linalg.inv(c2w) @ p44
+    out[:, :3, :4] = p44[:, :3, :4]
+    return out
+
+
+def llff_render_poses(poses, bds, path_zflat: bool = False, n_views: int = 120, n_rots: int = 2) -> np.ndarray:
+    """The spiral the loader derives from the recentred rig and its depth bounds (load_llff.py:294-328) -> fp32 [n, 3, 5].
+    ``path_zflat``: the reference halves ``N_views`` with a true division and then fails inside np.linspace on current numpy
+    (load_llff.py:321,184); here the count stays an integer."""
+    c2w = poses_avg(poses)
+    up = normalize(poses[:, :3, 1].sum(0))
+    close_depth, inf_depth = bds.min() * .9, bds.max() * 5.           # a "focus depth" between the bounds, in disparity
+    dt = .75
+    focal = 1. / (((1. - dt) / close_depth + dt / inf_depth))
+    zdelta = close_depth * .2
+    rads = np.percentile(np.abs(poses[:, :3, 3]), 90, 0)
+    if path_zflat:
+        zloc = -close_depth * .1
+        c2w[:3, 3] = c2w[:3, 3] + zloc * c2w[:3, 2]
+        rads[2] = 0.
+        n_rots = 1
+        n_views //= 2
+    return np.array(render_path_spiral(c2w, up, rads, focal, zdelta, zrate=.5, rots=n_rots, N=n_views)).astype(np.float32)
+
+
+def llff_cameras(raw_poses, raw_bds, bd_factor=.75, path_zflat: bool = False) -> Dict:
+    """Everything load_llff() derives from ``poses_bounds.npy`` (raw_poses [3,5,N], raw_bds [2,N]; load_llff.py:277-346) except
+    the images: axis reorder, rescale by the near bound, recentring, the render spiral, intrinsics.  Returns a dict with
+    ``poses`` [N,3,5], ``bds`` [N,2], ``render_poses`` [120,3,5], ``gt_extrinsic`` [N,3,4], ``gt_intrinsic`` [3,3], ``hw``."""
+    poses = np.concatenate([raw_poses[:, 1:2, :], -raw_poses[:, 0:1, :], raw_poses[:, 2:, :]], 1)
+    poses = np.moveaxis(poses, -1, 0).astype(np.float32)
+    bds = np.moveaxis(raw_bds, -1, 0).astype(np.float32)
+    sc = 1. if bd_factor is None else 1. / (bds.min() * bd_factor)
+    poses[:, :3, 3] *= sc
+    bds *= sc
+    poses = recenter_poses(poses)
+    render_poses = llff_render_poses(poses, bds, path_zflat)
+    poses = poses.astype(np.float32)
+    H, W, focal = poses[0, :3, -1]
+    H, W = int(H), int(W)
+    K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]])
+    return {"poses": poses, "bds": bds, "render_poses": render_poses, "gt_extrinsic": poses[:, :3, :4], "gt_intrinsic": K, "hw": [H, W]}
+
+
+# ---------------------------------------------------------------------------------------------------
 # eval / video harness
 # ---------------------------------------------------------------------------------------------------
 def _render_pose(model, posenc, K, pose, hw, opts):
@@ -155,12 +249,15 @@ def test(idx, i_test, posenc, model, test_imgs, gt_intrinsic, gt_extrinsic, hw, 
 
 
 def render(idx, posenc, model, gt_intrinsic, render_pose, hw, opts, *, log_dir: Optional[str] = None, save_dir: Optional[str] = None):
-    """Counterpart of test.py:111-174: renders every pose of ``render_pose`` (for blender/custom data the spherical path
-    from opts, test.py:119-124) and returns ``(rgbs uint8 [N,H,W,3], disps uint8 [N,H,W])`` -- the arrays the reference
+    """Counterpart of test.py:111-174: renders every pose of ``render_pose`` -- for blender/custom data the spherical path
+    from opts (test.py:119-124); for llff data the spiral the loader produced (``llff_render_poses``; [n,3,5] or [n,4,4],
+    the first 3x4 block is the camera) -- and returns ``(rgbs uint8 [N,H,W,3], disps uint8 [N,H,W])`` -- the arrays the reference
     hands to imageio.mimwrite (test.py:166-172).  ``save_dir``: also write ``{i}_rgb.png`` / ``{i}_disp.png``."""
     dev = next(model.parameters()).device if isinstance(model, torch.nn.Module) else model.device
     if getattr(opts, "data_type", None) in ("blender", "custom"):
         render_pose = get_render_pose(n_angle=opts.n_angle, single_angle=opts.single_angle, phi=opts.phi, nf=opts.nf)
+    elif render_pose is None:
+        raise MiNerfError("render(): llff data needs the loader's render poses (harness.llff_render_poses); got None")
     poses = torch.as_tensor(np.asarray(render_pose) if not isinstance(render_pose, torch.Tensor) else render_pose, dtype=torch.float32).to(dev)
     if isinstance(model, torch.nn.Module):
         model.eval()

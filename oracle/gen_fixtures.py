@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Generate the golden fixtures F1..F10 (F10: the callers either side of the path) by RUNNING THE REFERENCE.
+"""Generate the golden fixtures F1..F12 (F10/F12: the callers either side of the path; F11: the reference's own
+training-step gradients) by RUNNING THE REFERENCE.
 
 Runs only in the build container (needs /root/reference).  It imports the reference's hot-path
 modules unmodified, drives them on CPU through a small import shim, and writes inputs + the
@@ -16,7 +17,8 @@ Shim (container only):
     are known; draw order inside one render_rays call is t_rand then u).
   * ``Tensor.get_device`` -> 'cpu' (nerf_process.py:94, rays.py:23-24).
 
-Usage:  python oracle/gen_fixtures.py   (rewrites tests/golden/*.npz)
+Usage:  python oracle/gen_fixtures.py            (rewrites tests/golden/*.npz)
+        python oracle/gen_fixtures.py --f10 | --f11 | --f12   (one of the later fixtures only)
 """
 from __future__ import annotations
 
@@ -159,12 +161,122 @@ def f10_callers():
     save("F10_callers", **f)
 
 
+def f11_train_step(R):
+    """F11: the reference's own training step (train.py:53-70) on the F8 `legoA` inputs: batchify_rays_and_render_by_chunk with
+    gradients enabled, criterion = MSELoss (main.py:76) on the coarse and fine colours, loss = loss_c + loss_f, loss.backward().
+    The 48 parameter gradients of the 8x256 coarse/fine pair are the fixture (inputs are regenerated from seeds; the depths the
+    reference sampled are F8's legoA_z_c / legoA_z_f)."""
+    print("F11 training-step gradients")
+    enc_x, _ = R.posenc(10)
+    enc_d, _ = R.posenc(4)
+    Kl, Hl, Wl = synthetic.lego_camera()
+    with torch.no_grad():
+        o, d = R.rays.make_o_d(Wl, Hl, Kl, torch.from_numpy(synthetic.pose_spherical(0.0, -30.0, 4.0)[:3, :4]))
+    pix = synthetic.pixel_batch(Hl, Wl, 4096, 0)[:64]
+    ro, rd = o.reshape(-1, 3)[pix].contiguous(), d.reshape(-1, 3)[pix].contiguous()
+    f = {}
+    for tag, (D, W, seed, Sc, Nf) in (("d8w256", (8, 256, 0, 64, 128)), ("d4w128", (4, 128, 2, 24, 40))):
+        opts = make_opts(N_samples_c=Sc, N_samples_f=Nf)
+        m = ref_model(R, seed, D, W)
+        m.train()
+        t_rand = torch.from_numpy(counter_uniform(0, 0, 0, 64, Sc))
+        u = torch.from_numpy(counter_uniform(0, 1, 0, 64, Nf))
+        target = torch.from_numpy(np.random.RandomState(11).uniform(0, 1, (64, 3)).astype(np.float32))
+        criterion = torch.nn.MSELoss()                                         # main.py:76
+        with torch.enable_grad():
+            R.proxy.queue = [t_rand, u]
+            rgb_c, disp_c, rgb_f, disp_f = R.np.batchify_rays_and_render_by_chunk(ro, rd, m, (enc_x, enc_d), Hl, Wl, Kl, opts)   # train.py:53
+            loss_c = criterion(rgb_c, target)                                  # train.py:60
+            loss_f = criterion(rgb_f, target)                                  # train.py:64
+            loss = loss_c + loss_f                                             # train.py:66
+            loss.backward()                                                    # train.py:69
+        f.update({f"{tag}_target": target, f"{tag}_loss_c": loss_c.detach(), f"{tag}_loss_f": loss_f.detach(),
+                  f"{tag}_rgb_c": rgb_c.detach(), f"{tag}_rgb_f": rgb_f.detach(),
+                  f"{tag}_cfg": np.array([D, W, seed, Sc, Nf])})
+        # the depths the reference used (staged replay, no grad), so that a checker can pin them
+        with torch.no_grad():
+            R.proxy.queue = [t_rand]
+            emb_c, z_c, rdd = R.np.pre_process(torch.cat([ro, rd], -1), (enc_x, enc_d), opts, isFine=False)
+            _, _, _, w_c, _ = R.np.post_process(m(emb_c).reshape(64, Sc, 4), z_c, rdd)
+            R.proxy.queue = [u]
+            _, z_f, _ = R.np.pre_process(torch.cat([ro, rd], -1), (enc_x, enc_d), opts, z_vals=z_c, weights=w_c, isFine=True)
+        f[f"{tag}_z_c"], f[f"{tag}_z_f"] = z_c, z_f
+        n = 0
+        for k, p in m.named_parameters():
+            f[f"{tag}_grad.{k}"] = p.grad.detach().clone()
+            n += 1
+        print(f"  {tag}: loss_c {float(loss_c):.6f} loss_f {float(loss_f):.6f}, {n} gradient tensors")
+    save("F11_train_grads", **f)
+
+
+def f12_llff_spiral():
+    """F12: the LLFF camera path (dataset/load_llff.py:151-189 normalize / viewmatrix / poses_avg / render_path_spiral, consumed at
+    :294-328 and rendered by test.py:132-145).  load_llff.py is loaded by path under a stub package (its package __init__ drags in the
+    blender / custom loaders; `imageio` and `.colmap` are absent and unused here); `_load_data` (disk) is replaced by synthetic
+    poses_bounds so that the reference's own `load_llff()` runs end to end."""
+    print("F12 LLFF spiral")
+    import importlib.util
+    for name in ("imageio",):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    pkg = types.ModuleType("ref_dataset"); pkg.__path__ = [os.path.join(REF, "dataset")]
+    sys.modules["ref_dataset"] = pkg
+    col = types.ModuleType("ref_dataset.colmap"); col.gen_poses = lambda *a, **k: None
+    sys.modules["ref_dataset.colmap"] = col
+    spec = importlib.util.spec_from_file_location("ref_dataset.load_llff", os.path.join(REF, "dataset", "load_llff.py"))
+    ll = importlib.util.module_from_spec(spec)
+    sys.modules["ref_dataset.load_llff"] = ll
+    spec.loader.exec_module(ll)
+
+    rs = np.random.RandomState(2024)
+    N, H, W, focal = 11, 6, 8, 9.5
+    # forward-facing rig in the raw poses_bounds convention [3, 5, N] (columns: down, right, back, position, hwf)
+    raw = np.zeros((3, 5, N))
+    for i in range(N):
+        a, b, c = rs.normal(0, 0.08, 3)
+        Rx = np.array([[1, 0, 0], [0, np.cos(a), -np.sin(a)], [0, np.sin(a), np.cos(a)]])
+        Ry = np.array([[np.cos(b), 0, np.sin(b)], [0, 1, 0], [-np.sin(b), 0, np.cos(b)]])
+        Rz = np.array([[np.cos(c), -np.sin(c), 0], [np.sin(c), np.cos(c), 0], [0, 0, 1]])
+        raw[:, :3, i] = Rz @ Ry @ Rx
+        raw[:, 3, i] = rs.uniform(-1.5, 1.5, 3) * np.array([1.0, 0.6, 0.15])
+        raw[:, 4, i] = [H, W, focal]
+    bds_raw = np.stack([rs.uniform(1.1, 1.6, N), rs.uniform(7.0, 12.0, N)], 0)          # [2, N]
+    imgs = rs.uniform(0, 1, (H, W, 3, N))
+    f = dict(raw_poses=raw, raw_bds=bds_raw, hw=np.array([H, W]), focal=focal)
+    # path_zflat=True is not captured: the reference does `N_views /= 2` (load_llff.py:321) and hands the float to np.linspace,
+    # which raises TypeError under this numpy; main.py:43-44 never sets it
+    for tag, zflat in (("spiral", False),):
+        ll._load_data = lambda basedir, factor=None, colmap_relaunch=False: (raw.copy(), bds_raw.copy(), imgs.copy())
+        images, (K, ext), hw, (i_train, i_val, i_test), render_poses = ll.load_llff("unused", downsample=8, path_zflat=zflat)
+        f.update({f"{tag}_render_poses": render_poses, f"{tag}_K": K, f"{tag}_extrinsic": ext, f"{tag}_i_test": i_test, f"{tag}_i_train": i_train})
+    # the building blocks on their own (load_llff.py:151-189)
+    poses = np.concatenate([raw[:, 1:2, :], -raw[:, 0:1, :], raw[:, 2:, :]], 1)
+    poses = np.moveaxis(poses, -1, 0).astype(np.float32)
+    bds = np.moveaxis(bds_raw, -1, 0).astype(np.float32)
+    sc = 1. / (bds.min() * .75)
+    poses[:, :3, 3] *= sc
+    bds *= sc
+    rec = ll.recenter_poses(poses)
+    c2w = ll.poses_avg(rec)
+    v = rs.normal(0, 1, 3)
+    f.update(rec_poses=rec, rec_bds=bds, poses_avg=c2w, normalize_in=v, normalize_out=ll.normalize(v),
+             viewmatrix_out=ll.viewmatrix(rec[0, :3, 2], rec[1, :3, 1], rec[2, :3, 3]),
+             spiral_direct=np.array(ll.render_path_spiral(c2w, ll.normalize(rec[:, :3, 1].sum(0)), np.array([0.3, 0.2, 0.1]), 3.5, 0.2, zrate=.5, rots=2, N=9)))
+    save("F12_llff_spiral", **f)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_grad_enabled(False)
     R = load_reference()
     if "--f10" in sys.argv:                                     # only the callers fixture (F1-F9 untouched)
         f10_callers()
+        return
+    if "--f11" in sys.argv:
+        f11_train_step(R)
+        return
+    if "--f12" in sys.argv:
+        f12_llff_spiral()
         return
     rs = np.random.RandomState(1234)
 
@@ -340,6 +452,8 @@ def main():
                    f"{tag}_near": o9.near, f"{tag}_far": o9.far})
     save("F9_batchify", **f9)
     f10_callers()
+    f11_train_step(R)
+    f12_llff_spiral()
     print("done")
 
 

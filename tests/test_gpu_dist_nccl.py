@@ -1,0 +1,95 @@
+"""Multi-GPU legs on hardware.
+
+* `dist.render_frame` with backend "nccl" (= RCCL over xGMI) on 2 ranks, one GPU each: every rank's assembled frame must be
+  bit-identical to the 1-rank frame (rows sharded, jitter keyed on the global ray index, ONE all-gather).  Needs two GPUs:
+  skips itself on a one-GPU box (the driver's 8-GPU node runs it).
+* `python bench.py --gpus 2` without a torchrun environment: the parent only launches the two workers (it makes no GPU call);
+  rehearsed with BENCH_BACKEND=gloo so that both ranks can share the single GPU of the test box.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _scene(dev, H, W):
+    from types import SimpleNamespace
+    from nerf_pytorch_paeng_amd import synthetic, weights
+    sd = synthetic.make_state_dict(5, 4, 128)
+    packed = weights.PackedNeRF.from_state_dict(sd, dev)
+    K, _, _ = synthetic.lego_camera()
+    K = K.copy(); K[0, 0] *= W / 800.0; K[1, 1] *= W / 800.0; K[0, 2] = W / 2; K[1, 2] = H / 2
+    pose = synthetic.pose_spherical(20.0, -30.0, 4.0)
+    opts = SimpleNamespace(near=2.0, far=6.0, N_samples_c=16, N_samples_f=16, perturb=1.0, chunk_rays=4096, chunk_pts=524288,
+                           data_type="blender", gpu_ids=[0], rank=0)
+    return packed, K, pose, opts
+
+
+def _nccl_worker(rank, world, port, H, W, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda", rank)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        from nerf_pytorch_paeng_amd.dist import render_frame
+        packed, K, pose, opts = _scene(dev, H, W)
+        rgb, disp = render_frame(H, W, K, pose, packed, opts, seed=3)
+        torch.cuda.synchronize(dev)
+        np.save(os.path.join(out_dir, f"rgb_{rank}.npy"), rgb.cpu().numpy())
+        np.save(os.path.join(out_dir, f"disp_{rank}.npy"), disp.cpu().numpy())
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("H,W", [(24, 20), (25, 12)])      # even and ragged row splits
+def test_nccl_two_rank_frame_is_bit_identical_to_one_rank(tmp_path, H, W):
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL wants one GPU per rank); runs on the multi-GPU node")
+    mp.spawn(_nccl_worker, args=(2, _free_port(), H, W, str(tmp_path)), nprocs=2, join=True)
+    from nerf_pytorch_paeng_amd.dist import render_frame
+    dev = torch.device("cuda:0")
+    packed, K, pose, opts = _scene(dev, H, W)
+    rgb, disp = render_frame(H, W, K, pose, packed, opts, seed=3)        # no process group: one rank
+    for r in range(2):
+        np.testing.assert_array_equal(np.load(tmp_path / f"rgb_{r}.npy"), rgb.cpu().numpy())
+        np.testing.assert_array_equal(np.load(tmp_path / f"disp_{r}.npy"), disp.cpu().numpy())
+
+
+@pytest.mark.timeout(900)
+def test_bench_launches_its_own_workers():
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    if torch.cuda.device_count() < 2:
+        env["BENCH_BACKEND"] = "gloo"                   # two ranks on the one GPU: plumbing rehearsal
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--frames", "1",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=850)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                      # rank 0 prints ONE line
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["scaling"] == "strong"
+    assert j["config"]["rays_per_gpu"] == 2048 and j["value"] > 0 and j["value_weak"] > 0
+    assert j["frame_ms_800x800"] > 0 and j["roofline"]["frac"] <= 1.0

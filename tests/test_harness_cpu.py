@@ -66,3 +66,22 @@ def test_checkpoint_ingest_reference_format(tmp_path):
     torch.save({"idx": 1}, path)
     with pytest.raises(MiNerfError):
         harness.load_checkpoint(path)
+
+
+def test_bench_launcher_propagates_worker_failure():
+    """`python bench.py --gpus 2` without torchrun starts its own workers BEFORE touching the GPU; here (no GPU) both workers
+    exit with an error and the launcher must report it instead of hanging or printing a result."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("CPU-only check of the launcher's error path")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "needs an MI355X" in r.stderr and "worker rank" in r.stderr
+    assert not any(l.startswith("{") for l in r.stdout.splitlines())
