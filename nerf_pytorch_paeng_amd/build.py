@@ -23,6 +23,8 @@ ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
          # the MLP kernel's register-resident design needs its k-loops FULLY unrolled (static register indices)
          "-mllvm", "-pragma-unroll-threshold=1000000"]
+# mlp_bf16.hip manages the whole AGPR file by hand (explicit a[N] operands in asm statements): hipcc must not park spilled VGPRs there
+FILE_FLAGS = {"mlp_bf16.hip": ["-mllvm", "-amdgpu-spill-vgpr-to-agpr=0"]}
 
 
 def _hipcc() -> str:
@@ -45,7 +47,7 @@ def _compile(src: str, force: bool, extra=(), tag: str = "") -> str:
     if (not force and os.path.exists(obj) and os.path.getmtime(obj) >= os.path.getmtime(spath)
             and os.path.getmtime(obj) >= _deps_mtime()):
         return obj
-    cmd = [_hipcc(), *FLAGS, *extra, "-x", "hip", "-c", spath, "-o", obj]
+    cmd = [_hipcc(), *FLAGS, *FILE_FLAGS.get(src, []), *extra, "-x", "hip", "-c", spath, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")

@@ -425,3 +425,39 @@ def test_model_forward_is_differentiable_like_the_reference_module(D, W, skip, n
         for k, p in sub.named_parameters():
             assert rel_err(p.grad, psd[prefix + k].grad) < 2e-4, (prefix, k)
         assert all(p.grad is None for p in other.parameters())
+
+
+@pytest.mark.parametrize("tag", ["d8w256", "d4w128"])
+def test_F11_backward_matches_the_reference_training_step(golden, tag):
+    """The HIP backward against the gradients of the reference's OWN loss.backward() (fixture F11: train.py:53-70 executed by
+    oracle/gen_fixtures.py on 64 rays with injected randoms).  Depths are pinned to the ones the reference sampled."""
+    from nerf_pytorch_paeng_amd import train_path
+    from nerf_pytorch_paeng_amd.model import NeRF
+    from types import SimpleNamespace
+    g = golden("F11_train_grads")
+    D, W, seed, Sc, Nf = (int(v) for v in g[f"{tag}_cfg"])
+    sd = synthetic.make_state_dict(seed, D, W)
+    model = NeRF(D, W, 63, 27).to(DEV)
+    model.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+    K, H, Wd = synthetic.lego_camera()
+    pix = torch.from_numpy(synthetic.pixel_batch(H, Wd, 4096, 0)[:64]).to(DEV)
+    o, d = ops.make_o_d_pixels(Wd, H, K, synthetic.pose_spherical(0.0, -30.0, 4.0), pix)
+    rays = torch.cat([o, d], -1).contiguous()
+    opts = SimpleNamespace(near=2.0, far=6.0, N_samples_c=Sc, N_samples_f=Nf, perturb=1.0)
+    t_rand, u = torch.from_numpy(R.counter_uniform(0, 0, 0, 64, Sc)).to(DEV), torch.from_numpy(R.counter_uniform(0, 1, 0, 64, Nf)).to(DEV)
+    out = train_path.render_train(rays, model, opts, t_rand=t_rand, u=u,
+                                  z_override=(torch.from_numpy(g[f"{tag}_z_c"]).to(DEV), torch.from_numpy(g[f"{tag}_z_f"]).to(DEV)))
+    tgt = torch.from_numpy(g[f"{tag}_target"]).to(DEV)
+    loss_c, loss_f = torch.mean((out["rgb_c"] - tgt) ** 2), torch.mean((out["rgb_f"] - tgt) ** 2)          # train.py:60-66
+    (loss_c + loss_f).backward()
+    assert abs(loss_c.item() - float(g[f"{tag}_loss_c"])) < 2e-6 and abs(loss_f.item() - float(g[f"{tag}_loss_f"])) < 2e-6
+    assert float((out["rgb_f"].detach().cpu() - torch.from_numpy(g[f"{tag}_rgb_f"])).abs().max()) < 2e-5
+    worst, n = 0.0, 0
+    for k, p in model.named_parameters():
+        want = torch.from_numpy(g[f"{tag}_grad.{k}"])
+        e = rel_err(p.grad, want)
+        worst = max(worst, e)
+        assert e < 5e-5, (k, e)                     # relative to the tensor's largest entry
+        n += 1
+    assert n == (48 if D == 8 else 32)
+    print(f"F11 {tag}: worst per-tensor gradient error vs the reference {worst:.2e}")

@@ -85,3 +85,33 @@ def test_bench_launcher_propagates_worker_failure():
     assert r.returncode != 0
     assert "needs an MI355X" in r.stderr and "worker rank" in r.stderr
     assert not any(l.startswith("{") for l in r.stdout.splitlines())
+
+
+def test_F12_llff_spiral_path(golden):
+    """The LLFF camera path (dataset/load_llff.py:151-204, 277-346) against outputs of the reference's own load_llff() run on
+    synthetic poses_bounds (fixture F12): render spiral, recentred rig, intrinsics -- bit for bit."""
+    import numpy as np
+    from nerf_pytorch_paeng_amd import harness as Hn
+    g = golden("F12_llff_spiral")
+    cam = Hn.llff_cameras(g["raw_poses"], g["raw_bds"])
+    np.testing.assert_array_equal(cam["render_poses"], g["spiral_render_poses"])
+    assert cam["render_poses"].shape == (120, 3, 5) and cam["render_poses"].dtype == np.float32
+    np.testing.assert_array_equal(cam["gt_extrinsic"], g["spiral_extrinsic"])
+    np.testing.assert_array_equal(cam["gt_intrinsic"], g["spiral_K"])
+    np.testing.assert_array_equal(cam["poses"], g["rec_poses"])
+    np.testing.assert_array_equal(cam["bds"], g["rec_bds"])
+    assert cam["hw"] == [int(v) for v in g["hw"]]
+    # building blocks.  The loader's arrays keep the memory order of poses_bounds ([3,5,N] moved to [N,3,5] as a view), and
+    # numpy's reductions over axis 0 round differently for different strides: rebuild that layout for the bit-exact check
+    rec = np.moveaxis(np.ascontiguousarray(np.moveaxis(g["rec_poses"], 0, -1)), -1, 0)
+    np.testing.assert_array_equal(Hn.poses_avg(rec), g["poses_avg"])
+    np.testing.assert_allclose(Hn.poses_avg(g["rec_poses"]), g["poses_avg"], atol=1e-7)
+    np.testing.assert_array_equal(Hn.normalize(g["normalize_in"]), g["normalize_out"])
+    np.testing.assert_array_equal(Hn.viewmatrix(rec[0, :3, 2], rec[1, :3, 1], rec[2, :3, 3]), g["viewmatrix_out"])
+    sp = np.array(Hn.render_path_spiral(g["poses_avg"], Hn.normalize(rec[:, :3, 1].sum(0)), np.array([0.3, 0.2, 0.1]), 3.5, 0.2, zrate=.5, rots=2, N=9))
+    np.testing.assert_array_equal(sp, g["spiral_direct"])
+    np.testing.assert_array_equal(Hn.recenter_poses(rec), Hn.recenter_poses(rec))
+    # properties: every spiral camera is orthonormal and looks at the focus point; the flat path halves the view count
+    Rm = cam["render_poses"][:, :3, :3].astype(np.float64)
+    np.testing.assert_allclose(np.einsum("nij,nik->njk", Rm, Rm), np.broadcast_to(np.eye(3), (120, 3, 3)), atol=1e-6)
+    assert Hn.llff_render_poses(cam["poses"], cam["bds"], path_zflat=True).shape == (60, 3, 5)

@@ -176,3 +176,29 @@ def test_flat_parameter_order_and_pack_maps():
         out[nz] = flat[(mp[nz] - 1).long()]
         assert torch.equal(out[256:], host[256:])
         assert int(mp.min()) == 0 and int(mp.max()) <= flat.numel()
+
+
+# ---------------------------------------------------------------------------------------------------
+# bf16 variant: output-tile-major stream, heads on the matrix pipe
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("D,skip", [(8, 4), (3, -1), (4, 1), (7, 5)])
+def test_bf16_blob_emulation_matches_bf16_oracle(D, skip):
+    """The bf16 packer + the kernel's operand bookkeeping (tests/blob_emulator_bf16.py walks the stream as mlp_bf16.hip does) against
+    the oracle with the same rounding points (R.mlp_forward_bf16), both accumulating in fp64."""
+    from tests.blob_emulator_bf16 import EmuBf16
+    W = 256
+    sd = synthetic.make_state_dict(5, D, W, skips=(skip,) if skip >= 0 else ())
+    net = weights.infer_net(sd)
+    assert net.skip == (skip if skip + 1 < D else skip) or skip < 0
+    blob = ops.pack_module(sd, "model_coarse.", net, bf16=True).numpy()
+    rs = np.random.RandomState(2)
+    ray = rs.normal(size=6)
+    z = np.sort(rs.uniform(2, 6, 32))
+    p = (ray[:3, None] + ray[3:, None] * z[None, :]).T.astype(np.float32)           # [32, 3]
+    v = ray[3:] / np.linalg.norm(ray[3:])
+    g = R.posenc(torch.from_numpy(v[None]), 4)[0].numpy()
+    emu = EmuBf16(blob)
+    out = emu.tile(p.astype(np.float64), g)
+    x = torch.cat([R.posenc(torch.from_numpy(p).double(), 10), torch.from_numpy(g)[None].expand(32, 27)], -1)
+    ref = R.mlp_forward_bf16(sd, "model_coarse.", x, D, 63, 27, skips=(skip,) if skip >= 0 else (), dtype=torch.float64).numpy()
+    np.testing.assert_allclose(out, ref, atol=1e-9, rtol=1e-9)
