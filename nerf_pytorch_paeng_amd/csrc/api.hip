@@ -19,6 +19,29 @@ int hip_fail(hipError_t e, const char* what) {
     return MI_NERF_EHIP;
 }
 
+// ---- per-device launch state -----------------------------------------------------------------------
+int device_cus() {
+    static int cus[MN_MAX_DEVICES] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    int& c = cus[dev & (MN_MAX_DEVICES - 1)];
+    if (c <= 0) {
+        hipDeviceProp_t prop;
+        c = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    return c;
+}
+int ensure_lds_opt_in(LdsOptIn& state, const void* kernel) {
+    int dev = 0;
+    MN_HIP(hipGetDevice(&dev));
+    bool& done = state.done[dev & (MN_MAX_DEVICES - 1)];
+    if (!done) {
+        MN_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        done = true;
+    }
+    return MI_NERF_OK;
+}
+
 // ---- implemented in the other translation units --------------------------------------------------
 int pack_fp32(const mi_nerf_net*, const mi_nerf_params*, void*, size_t);
 int pack_bf16(const mi_nerf_net*, const mi_nerf_params*, void*, size_t);

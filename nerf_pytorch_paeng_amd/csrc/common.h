@@ -30,6 +30,13 @@ int hip_fail(hipError_t e, const char* what);
         if (e__ != hipSuccess) return ::minerf::hip_fail(e__, "launch " name); \
     } while (0)
 
+// Per-DEVICE launch state (a process may drive several GPUs: the 160 KB dynamic-LDS opt-in is an attribute of the function ON a
+// device, and the CU count is a property of the device): small arrays indexed by the current device ordinal.
+constexpr int MN_MAX_DEVICES = 64;
+struct LdsOptIn { bool done[MN_MAX_DEVICES]; };
+int device_cus();                                             // multiProcessorCount of the current device (cached per device)
+int ensure_lds_opt_in(LdsOptIn& state, const void* kernel);  // hipFuncSetAttribute(MaxDynamicSharedMemorySize = 160 KB), once per device
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

@@ -51,7 +51,11 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4b __attribute__((ext_vector_type(4)));
 
 constexpr int NP = 2;                                      // point tiles per wave
+#ifdef MN_BF16_DA
+constexpr int DA = MN_BF16_DA;                             // A/B variant (tools/ab_probe.py)
+#else
 constexpr int DA = 4;                                      // A-operand pipeline depth (fragments in flight)
+#endif
 constexpr int BSLOT_QUADS = 32;
 constexpr int BSLOT_BYTES = BSLOT_QUADS * QUAD_BYTES;      // 32 KiB
 constexpr int BNSLOT = 3;
@@ -209,7 +213,22 @@ struct MlpArgsB {
     int S, tpr, D, skip_layer;
     unsigned stream_bytes, side_floats;
     unsigned o_bias_trunk, o_bias_feat, o_bias_d, o_head_b, o_wdir_t;
+    unsigned long long* diag;   // MN_DIAG builds only: per-wave cycle sums of the kernel's segments
 };
+
+#ifdef MN_DIAG
+// diagnostic build only (never shipped, never timed): s_memtime stamps around the kernel's segments (read SHARES, not totals)
+__device__ __forceinline__ unsigned long long bstamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define BSTAMP(i) do { const unsigned long long t_ = bstamp(); seg[i] += t_ - tprev; tprev = t_; } while (0)
+#else
+#define BSTAMP(i) do {} while (0)
+#endif
 
 struct BRing {
     const char* sbase;      // stream + wave's 8 KiB share
@@ -219,39 +238,32 @@ struct BRing {
     unsigned read_slot;
 };
 
-template <int IMM>
-__device__ __forceinline__ void bdma16(const char* sbase_in, unsigned voff, unsigned lds_in) {
-    // both are wave-uniform by construction; under register pressure hipcc may keep loop-carried uniform values in VGPRs, and an
-    // "s" operand is not legalised for inline asm: pin them to SGPRs here (folds away when they already are)
-    const unsigned lds_addr = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_in);
-    const unsigned long long sb_in = (unsigned long long)sbase_in;       // the builtin returns a SIGNED int: widen as unsigned
-    const unsigned sb_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)sb_in);
-    const unsigned sb_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(sb_in >> 32));
-    const unsigned long long sb = ((unsigned long long)sb_hi << 32) | (unsigned long long)sb_lo;
-    const char* sbase = (const char*)sb;
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %3\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %2 offset:%4\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(voff), "s"(sbase), "s"(lds_addr), "i"(IMM)
-        : "memory");
+// LDS-DMA of the weight stream.  One global_load_lds_dwordx4 moves 64 lanes x 16 B = one 1 KiB quad: global address = per-lane
+// VGPR pair + instruction offset, LDS destination = M0 + instruction offset + lane * 16.  M0 is written twice per slot (each
+// wave's 8 KiB share = two 4 KiB halves, the 13-bit offset reaches 4 KiB) and is NOT saved / restored around each DMA: nothing
+// else in this kernel touches M0 (hipcc uses it only for LDS-direct / GWS / sendmsg / movrel instructions, none of which occur
+// here; tests/test_packing_cpu.py disassembles the object and checks that every M0 write is ours).  Earlier form: SGPR base +
+// save/restore per DMA = ten instructions per quad, 8 % of the kernel (ablation build, profiles/r02_bf16_ablation.json).
+__device__ __forceinline__ void bdma_set_m0(unsigned lds_in) {
+    const unsigned lds_addr = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_in);      // wave-uniform by construction; pin to an SGPR
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(lds_addr) : "memory");
 }
-// DMA number i of the slot being fetched: 8 KiB per wave; the 13-bit instruction offset reaches 4 KiB, so the
-// second half goes through a +4 KiB base
+template <int IMM>
+__device__ __forceinline__ void bdma16(const char* gaddr_lane) {
+    asm volatile("global_load_lds_dwordx4 %0, off offset:%1" ::"v"(gaddr_lane), "i"(IMM) : "memory");
+}
+// DMA number i (0..7) of the slot being fetched
 __device__ __forceinline__ void bring_dma(const BRing& r, int i) {
-    const char* g = r.sbase + r.fetch_off;
-    if (i == 0) bdma16<0>(g, r.voff, r.fetch_lds);
-    else if (i == 1) bdma16<1024>(g, r.voff, r.fetch_lds);
-    else if (i == 2) bdma16<2048>(g, r.voff, r.fetch_lds);
-    else if (i == 3) bdma16<3072>(g, r.voff, r.fetch_lds);
-    else if (i == 4) bdma16<0>(g + 4096, r.voff, r.fetch_lds + 4096);
-    else if (i == 5) bdma16<1024>(g + 4096, r.voff, r.fetch_lds + 4096);
-    else if (i == 6) bdma16<2048>(g + 4096, r.voff, r.fetch_lds + 4096);
-    else if (i == 7) bdma16<3072>(g + 4096, r.voff, r.fetch_lds + 4096);
+#ifdef MN_BF16_NODMA
+    return;
+#endif
+    const char* g = r.sbase + r.fetch_off + r.voff + (i >= 4 ? 4096 : 0);
+    if (i == 0) bdma_set_m0(r.fetch_lds);
+    if (i == 4) bdma_set_m0(r.fetch_lds + 4096);
+    if ((i & 3) == 0) bdma16<0>(g);
+    else if ((i & 3) == 1) bdma16<1024>(g);
+    else if ((i & 3) == 2) bdma16<2048>(g);
+    else bdma16<3072>(g);
 }
 __device__ __forceinline__ void bring_next_fetch(BRing& r) {
     r.fetch_off += BSLOT_BYTES;
@@ -265,7 +277,9 @@ __device__ __forceinline__ void bring_next_fetch(BRing& r) {
 // they can only make this wait stricter.
 __device__ __forceinline__ void bring_advance(BRing& r) {
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#ifndef MN_BF16_NOBARRIER                                    // ablation builds (timing experiments only, results are garbage)
     __syncthreads();
+#endif
     bring_next_fetch(r);
     r.read_slot = (r.read_slot + 1 == BNSLOT) ? 0 : r.read_slot + 1;
 }
@@ -333,19 +347,32 @@ __device__ __forceinline__ void mfma_acc(f32x16& acc, const u32x4b& afrag, const
     asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(afrag), "v"(bfrag));
 }
 
-// item I (0..7) of a finished 32x32 tile: accumulator registers 2I, 2I+1 -> register R0 + I of the fragment file, where R0 is the
-// first register of fragment 2T (fragments 2T and 2T+1 are adjacent: dwords 0..3 and 4..7)
-template <bool RELU, int R0, int I>
-__device__ __forceinline__ void pack_item(const f32x16& acc) {
-    agpr_write<R0 + I>(pack2<RELU>(acc[2 * I], acc[2 * I + 1]));
+// Pair J (0..3) of a finished 32x32 tile: accumulator registers 4J..4J+3 -> two packed dwords -> registers R0 + 2J, R0 + 2J + 1 of the
+// fragment file, where R0 is the first register of fragment 2T (fragments 2T and 2T+1 are adjacent: dwords 0..3 and 4..7).
+// Two dwords per statement, interleaved, so that no instruction reads the result of the one in front of it (a lone
+// cvt -> max -> write chain costs a wait state per link).
+template <bool RELU, int R0, int J>
+__device__ __forceinline__ void pack_pair(const f32x16& acc) {
+    unsigned t0, t1;
+    if (RELU)
+        asm volatile("v_cvt_pk_bf16_f32 %0, %2, %3\n\tv_cvt_pk_bf16_f32 %1, %4, %5\n\tv_pk_max_i16 %0, %0, 0\n\tv_pk_max_i16 %1, %1, 0\n\t"
+                     "v_accvgpr_write_b32 a[%6], %0\n\tv_accvgpr_write_b32 a[%7], %1"
+                     : "=&v"(t0), "=&v"(t1) : "v"(acc[4 * J]), "v"(acc[4 * J + 1]), "v"(acc[4 * J + 2]), "v"(acc[4 * J + 3]), "n"(R0 + 2 * J), "n"(R0 + 2 * J + 1));
+    else
+        asm volatile("v_cvt_pk_bf16_f32 %0, %2, %3\n\tv_cvt_pk_bf16_f32 %1, %4, %5\n\t"
+                     "v_accvgpr_write_b32 a[%6], %0\n\tv_accvgpr_write_b32 a[%7], %1"
+                     : "=&v"(t0), "=&v"(t1) : "v"(acc[4 * J]), "v"(acc[4 * J + 1]), "v"(acc[4 * J + 2]), "v"(acc[4 * J + 3]), "n"(R0 + 2 * J), "n"(R0 + 2 * J + 1));
 }
-// The NP x 8 items of the previous job's packing (point tile 0 first) dealt over the first `groups` groups of a job
-__host__ __device__ constexpr int pack_lo(int ks, int groups) { return ks >= groups ? NP * 8 : (NP * 8 * ks) / groups; }
+// The NP x 4 pairs of the previous job's packing (point tile 0 first) dealt over the first `groups` groups of a job
+__host__ __device__ constexpr int pack_lo(int ks, int groups) { return ks >= groups ? NP * 4 : (NP * 4 * ks) / groups; }
 template <bool RELU, int SET, int F0, int KS, int GROUPS>
 __device__ __forceinline__ void pack_group(const f32x16 (&prev)[NP]) {
+#ifdef MN_BF16_NOPACK
+    return;
+#endif
     static_for<pack_lo(KS, GROUPS), pack_lo(KS + 1, GROUPS)>([&](auto w_c) __attribute__((always_inline)) {
-        constexpr int w = decltype(w_c)::value, p = w >> 3, i = w & 7;
-        pack_item<RELU, frag_reg(SET, p, F0), i>(prev[p]);
+        constexpr int w = decltype(w_c)::value, p = w >> 2, j = w & 3;
+        pack_pair<RELU, frag_reg(SET, p, F0), j>(prev[p]);
     });
 }
 
@@ -368,15 +395,27 @@ template <int Q0, int KS, int QEND, int QPAD, typename CSel, typename BSrc, type
 __device__ __forceinline__ void job(f32x16 (&acc)[NP], CSel csel, BSrc bsrc, u32x4b (&a)[DA], const char* smem, BRing& ring, int lane, Hook hook) {
     static_for<0, KS>([&](auto ks_c) __attribute__((always_inline)) {
         constexpr int ks = decltype(ks_c)::value;
+        // In-order issue: the wave sits at the SECOND MFMA until the matrix pipe has taken the first (32 cycles), so whatever
+        // follows both MFMAs has only the second one's 24 free cycles.  The work of a group is therefore split: the ring
+        // bookkeeping (advance, one DMA, the A-pipeline refill of the register the PREVIOUS group consumed) rides behind the first
+        // MFMA, the hook behind the second.
+        constexpr int q0 = Q0 + ks + DA - 1;                              // stream position being read into register q0 % DA
+        constexpr int qn = (q0 >= QEND) ? q0 + QPAD : q0;
         static_for<0, NP>([&](auto p_c) __attribute__((always_inline)) {
             constexpr int p = decltype(p_c)::value;
             if constexpr (ks == 0) mfma_first(acc[p], a[(Q0 + ks) % DA], bsrc(p_c, ks_c), csel(p));
             else mfma_acc(acc[p], a[(Q0 + ks) % DA], bsrc(p_c, ks_c));
+            if constexpr (p == 0) {
+                if constexpr (qn % BSLOT_QUADS == 0) bring_advance(ring);
+                a[q0 % DA] = bring_read(smem, ring, lane, qn % BSLOT_QUADS);
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
         });
-        constexpr int qn = (Q0 + ks + DA >= QEND) ? Q0 + ks + DA + QPAD : Q0 + ks + DA;
-        if constexpr (qn % BSLOT_QUADS == 0) bring_advance(ring);
-        a[(Q0 + ks) % DA] = bring_read(smem, ring, lane, qn % BSLOT_QUADS);
         hook(ks_c);
+        // the C operand of the first MFMAs is dead for the compiler once they are issued, but the matrix pipe reads it for a few more
+        // cycles: keep its registers out of the allocator's hands until the next group
+        if constexpr (ks == 0) { asm volatile("" ::"v"(csel(0))); asm volatile("" ::"v"(csel(NP - 1))); }
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
     });
@@ -417,7 +456,7 @@ void mlp_bf16_kernel(const MlpArgsB a) {
     u32x4b aq[DA];
     bring_advance(ring);                                     // also publishes the side tables (barrier)
 #pragma unroll
-    for (int i = 0; i < DA; ++i) aq[i] = bring_read(smem, ring, lane, i);
+    for (int i = 0; i < DA - 1; ++i) aq[i] = bring_read(smem, ring, lane, i);      // position q is read while group q - (DA - 1) computes
 
     // ---- tile walk: a wave takes PAIRS of consecutive 32-sample tiles.  Ray-major (ppr > 0): a wave walks whole rays, so the
     // hoisted view-direction term is computed once per ray; flat otherwise.  Inputs of the next pair are loaded a pair ahead.
@@ -489,6 +528,10 @@ void mlp_bf16_kernel(const MlpArgsB a) {
         });
     };
 
+#ifdef MN_DIAG
+    unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = bstamp();
+#endif
     for (unsigned it = 0; it < a.n_iter; ++it) {
         // ---- prologue: this pair's points, gamma(x) fragments, hoisted view-direction bias ------------------------------------
         unsigned tile[NP]; bool valid[NP]; size_t out_idx[NP];
@@ -582,6 +625,7 @@ void mlp_bf16_kernel(const MlpArgsB a) {
                 }
             }
         }
+        BSTAMP(0);   // prologue
         // ---- layer 0: 8 jobs of 4 k-steps over gamma(x) (VGPR fragments), output into set 0 -----------------------------------------
         {
             const float* b0 = side + a.o_bias_trunk + 4 * hh;
@@ -602,6 +646,7 @@ void mlp_bf16_kernel(const MlpArgsB a) {
                 cin = cnext;
             });
         }
+        BSTAMP(1);   // layer 0
         // ---- trunk layers 1..D-1 ping-pong between the two fragment sets with a static polarity (pairs 0->1, 1->0) --------------------
         auto layer_01 = [&](int l) __attribute__((always_inline)) {
             const float* bias = side + a.o_bias_trunk + l * W;
@@ -707,9 +752,16 @@ void mlp_bf16_kernel(const MlpArgsB a) {
                     *(f32x4*)(a.out + out_idx[p] * 4) = o;
                 }
         };
-        if (l < a.D) { layer_01(l); tail(IC<1>{}); }
-        else tail(IC<0>{});
+        if (l < a.D) { layer_01(l); BSTAMP(2); tail(IC<1>{}); }
+        else { BSTAMP(2); tail(IC<0>{}); }
+        BSTAMP(3);   // tail
     }
+#ifdef MN_DIAG
+    if (a.diag && lane == 0) {
+        unsigned long long* d = a.diag + ((size_t)blockIdx.x * 4 + wave) * 8;
+        for (int i = 0; i < 8; ++i) d[i] = seg[i];
+    }
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 }
@@ -736,20 +788,12 @@ int mlp_rays_bf16(const mi_nerf_net* net, const void* packed_dev, const float* r
     const size_t lds = BRING_BYTES + (size_t)a.side_floats * 4 + 4 * NP * (256 / 2) * 4 + 4 * NP * enc_ksteps16(10) * QUAD_BYTES;
     MN_CHECK_ARG(lds <= 160 * 1024, "LDS budget exceeded: %zu bytes", lds);
     auto kern = mlp_bf16_kernel<256, 10, 4>;
-    int dev = 0;
-    MN_HIP(hipGetDevice(&dev));
-    static bool attr_set[64] = {};
-    static int cus_of[64] = {};
-    const int di = dev & 63;
-    if (!attr_set[di]) {                                     // per device: the attribute belongs to the function ON a device
-        MN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        hipDeviceProp_t prop;
-        cus_of[di] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-        attr_set[di] = true;
-    }
+    static LdsOptIn opt_in = {};
+    if (int rc = ensure_lds_opt_in(opt_in, (const void*)kern)) return rc;
+    const int n_cus = device_cus();
     const long long n_pairs = (n_wtiles + 1) / 2;
     const long long n_wg = (n_pairs + 3) / 4;
-    const int grid = (int)(n_wg < cus_of[di] ? n_wg : cus_of[di]);
+    const int grid = (int)(n_wg < n_cus ? n_wg : n_cus);
     const long long NW = (long long)grid * 4;
     if (a.tpr % 2 == 0 && n_rays >= NW) {                    // ray-major: every wave gets whole rays
         a.ppr = (unsigned)(a.tpr / 2);
@@ -758,6 +802,33 @@ int mlp_rays_bf16(const mi_nerf_net* net, const void* packed_dev, const float* r
         a.ppr = 0;
         a.n_iter = (unsigned)((n_pairs + NW - 1) / NW);
     }
+#ifdef MN_DIAG
+    {   // diagnostic build: run once with stamps and print the per-segment averages (cycles per tile PAIR per wave)
+        unsigned long long* dbuf = nullptr;
+        const size_t n = (size_t)grid * 4 * 8;
+        MN_HIP(hipMalloc(&dbuf, n * 8));
+        MN_HIP(hipMemsetAsync(dbuf, 0, n * 8, st));
+        a.diag = dbuf;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
+        MN_HIP(hipStreamSynchronize(st));
+        std::vector<unsigned long long> hbuf(n);
+        MN_HIP(hipMemcpy(hbuf.data(), dbuf, n * 8, hipMemcpyDeviceToHost));
+        (void)hipFree(dbuf);
+        static const char* names[4] = {"prologue", "layer0", "trunk", "tail"};
+        static const double ideal[4] = {0, 2048, 7 * 8192 + 2048, 216 * 64};
+        double tot = 0;
+        fprintf(stderr, "[mn_diag bf16] grid=%d pairs/wave=%u  cycles per pair (mean over waves; ideal MFMA cycles in brackets):\n", grid, a.n_iter);
+        for (int sgi = 0; sgi < 4; ++sgi) {
+            double sum = 0;
+            for (size_t w = 0; w < (size_t)grid * 4; ++w) sum += (double)hbuf[w * 8 + sgi];
+            const double per = sum / ((double)grid * 4) / (double)a.n_iter;
+            tot += per;
+            fprintf(stderr, "[mn_diag bf16]   %-10s %10.0f  [%6.0f]\n", names[sgi], per, ideal[sgi]);
+        }
+        fprintf(stderr, "[mn_diag bf16]   %-10s %10.0f  [%6.0f]\n", "total", tot, ideal[1] + ideal[2] + ideal[3]);
+        return MI_NERF_OK;
+    }
+#endif
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
     MN_LAUNCH_CHECK("mlp_bf16_kernel");
     return MI_NERF_OK;

@@ -369,16 +369,7 @@ static int check_net(const mi_nerf_net* net) {
     return MI_NERF_OK;
 }
 
-static int num_cus() {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
-    }
-    return cus;
-}
+static int num_cus() { return device_cus(); }
 
 template <int W, int MODE, bool STASH = false>
 static int launch(const MlpArgs& args_in, long long n_wtiles, hipStream_t st) {
@@ -386,11 +377,8 @@ static int launch(const MlpArgs& args_in, long long n_wtiles, hipStream_t st) {
     const size_t lds = RING_BYTES + (size_t)args.side_floats * 4 + 4 * (W / 2) * 4;
     MN_CHECK_ARG(lds <= 160 * 1024, "LDS budget exceeded: %zu bytes", lds);
     auto kern = mlp_fp32_kernel<W, MODE, 10, 4, STASH>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        MN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    static LdsOptIn opt_in = {};                              // per template instantiation, per device
+    if (int rc = ensure_lds_opt_in(opt_in, (const void*)kern)) return rc;
     const long long n_wg = (n_wtiles + 3) / 4;
     const int grid = (int)(n_wg < (long long)num_cus() ? n_wg : (long long)num_cus());
     {   // the tile walk (see the kernel): ray-major once every wave of the grid gets at least one whole ray

@@ -147,35 +147,36 @@ void mlp_dgrad_kernel(const DgradArgs a) {
             auto hook = [&](int kq, int t) __attribute__((always_inline)) { if (t == NT - 1) store_chunk(h, kq, row); };
             gemm_part<NT, HN, NT, AL>(acc, h, aq, smem, ring, lane, hook);
         }
-        // ---- trunk, last layer first ----
-#pragma unroll 1
-        for (int l = a.D - 1;; --l) {
+        // ---- trunk, last layer first.  The ReLU' epilogue of layer l produces delta_l in `h`; the loop body is [GEMM with
+        // W_l^T, rows of delta_l stored from its hook] [epilogue of layer l-1].  The first epilogue (the trunk output also feeds
+        // the density head: + dens_w * d sigma, rank 1 on the VALU) is peeled, so the loop holds ONE epilogue variant (with both
+        // in the loop body hipcc spilled 124 bytes per lane around it).
+        {
             const unsigned mw[4] = {mhv[0], mhv[1], mhv[2], mhv[3]};
-            if (l > 0) mhv = *(const u32x4*)(a.mask_h + (((long long)(l - 1) * a.n_wtiles + wt) * 64 + lane) * 4);   // a layer ahead
-            if (l == a.D - 1) {         // the trunk output also feeds the density head: + dens_w * d sigma (rank 1, VALU)
-                const float ds = dr[3];
+            if (a.D > 1) mhv = *(const u32x4*)(a.mask_h + (((long long)(a.D - 2) * a.n_wtiles + wt) * 64 + lane) * 4);   // a layer ahead
+            const float ds = dr[3];
 #pragma unroll
-                for (int q = 0; q < 4 * NT; ++q) {
-                    const f32x4 wv = *(const f32x4*)(dw + 8 * q + 4 * hh);
+            for (int q = 0; q < 4 * NT; ++q) {
+                const f32x4 wv = *(const f32x4*)(dw + 8 * q + 4 * hh);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        h[4 * q + e] = mask_apply(__builtin_fmaf(wv[e], ds, acc[q >> 2][4 * (q & 3) + e]), q, e, mw);    // ReLU'
-                }
-            } else {
-#pragma unroll
-                for (int q = 0; q < 4 * NT; ++q)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) h[4 * q + e] = mask_apply(acc[q >> 2][4 * (q & 3) + e], q, e, mw);          // ReLU'
+                for (int e = 0; e < 4; ++e)
+                    h[4 * q + e] = mask_apply(__builtin_fmaf(wv[e], ds, acc[q >> 2][4 * (q & 3) + e]), q, e, mw);    // ReLU'
             }
+        }
+#pragma unroll 1
+        for (int l = a.D - 1; l > 0; --l) {
             float* row = a.delta_h + ((long long)l * a.P + idx) * W + 4 * hh;
-            if (l == 0) {
-                store_rows<NT>(h, row, valid);      // no GEMM consumes delta_0 (there is no gradient w.r.t. gamma(x))
-                break;
-            }
             acc_zero<NT>(acc);
             auto hook = [&](int kq, int t) __attribute__((always_inline)) { if (t == NT - 1) store_chunk(h, kq, row); };
             gemm_part<NT, HN, NT, AL>(acc, h, aq, smem, ring, lane, hook);          // W_l[:, h-block]^T delta_l
+            const unsigned mw[4] = {mhv[0], mhv[1], mhv[2], mhv[3]};
+            if (l > 1) mhv = *(const u32x4*)(a.mask_h + (((long long)(l - 2) * a.n_wtiles + wt) * 64 + lane) * 4);       // a layer ahead
+#pragma unroll
+            for (int q = 0; q < 4 * NT; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) h[4 * q + e] = mask_apply(acc[q >> 2][4 * (q & 3) + e], q, e, mw);              // ReLU'
         }
+        store_rows<NT>(h, a.delta_h + idx * W + 4 * hh, valid);      // no GEMM consumes delta_0 (there is no gradient w.r.t. gamma(x))
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -201,7 +202,7 @@ struct ReduceBatch {                      // where each product of a batch goes 
 
 // masked lanes / rows past the slice end load zeros from here WITHOUT a branch (a value select after the load makes
 // hipcc wrap every load in its own exec-masked block with an immediate s_waitcnt: 6x slower).  Never written.
-__device__ float g_zero16[4];
+__device__ __attribute__((aligned(16))) float g_zero16[4];      // read through f32x4*: 16-byte aligned
 
 // 256 x 256 block of dW per workgroup: 2x2 waves, each 4x4 MFMA tiles (all 256 accumulator registers).
 // Operand fetch: ONE 16-byte load per lane per point pair and operand: lane i takes columns 4i..4i+3, i.e. MFMA tile
@@ -311,7 +312,7 @@ struct NarrowArgs {
 template <int WQ, int NN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
 void wgrad_narrow_kernel(const NarrowArgs a) {
-    constexpr int U = (WQ * NN == 4) ? 4 : 6;      // k-steps per pipeline stage: 3 register sets next to 64 WQ NN accumulators
+    constexpr int U = (WQ == 2) ? 4 : 6;      // k-steps per pipeline stage: 3 register sets next to 64 WQ NN accumulators, no scratch
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 31, kh = lane >> 5;
@@ -327,7 +328,7 @@ void wgrad_narrow_kernel(const NarrowArgs a) {
     long long sw[WQ];
 #pragma unroll
     for (int q = 0; q < WQ; ++q) {
-        wok[q] = active && 128 * q + 4 * i < a.Mw;
+        wok[q] = active && pb + kh < a.P && 128 * q + 4 * i < a.Mw;
         pw[q] = wok[q] ? a.wide + (pb + kh) * a.ldw + 128 * q + 4 * i : g_zero16;
         sw[q] = wok[q] ? (long long)a.ldw * 2 : 0;
     }
@@ -350,14 +351,17 @@ void wgrad_narrow_kernel(const NarrowArgs a) {
     for (int q = 0; q < NN; ++q) nsum[q] = 0.0f;
 
     // three register sets rotated by name, loads behind each k-step's MFMAs, rows past the slice end zeroed in both
-    // operands: see wgrad_big_kernel.  The wide operand may be read up to five groups past the slice end (padding from
-    // train_layout()); the narrow operand can be a caller tensor (d_raw), so its address is clamped to the zero buffer.
+    // operands: see wgrad_big_kernel.  The load pipeline runs up to five groups ahead of the slice end; neither operand is ever
+    // read outside its P rows (narrow: requests for rows >= P are switched to the zero buffer by ADDRESS; wide: the pointer stops).
     struct Set { f32x4 w[U][WQ]; float n[U][NN]; };
     Set c, nx, f;
     long long row = pb + kh;                 // next row to request for this lane half
     auto request = [&](Set& S, int u) __attribute__((always_inline)) {
+        // the wide pointer stops advancing at this lane half's last row (the re-read values are zeroed below like every row past
+        // the slice end): the pipeline runs up to five groups ahead of the data but never reads past row P - 1
+        const long long keep = (row + 2 < a.P) ? -1LL : 0LL;
 #pragma unroll
-        for (int q = 0; q < WQ; ++q) { S.w[u][q] = *(const f32x4*)pw[q]; pw[q] += sw[q]; }
+        for (int q = 0; q < WQ; ++q) { S.w[u][q] = *(const f32x4*)pw[q]; pw[q] += sw[q] & keep; }
         const bool in = row < a.P;
 #pragma unroll
         for (int q = 0; q < NN; ++q) {
@@ -528,16 +532,7 @@ __global__ __launch_bounds__(256) void pack_apply_kernel(const int32_t* __restri
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
-static int num_cus_t() {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
-    }
-    return cus;
-}
+static int num_cus_t() { return device_cus(); }
 
 static inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 // wgrad_narrow_kernel's load pipeline runs up to 5 groups x 12 rows x 1 KiB past the end of its wide operand
@@ -667,11 +662,8 @@ static int launch_dgrad(const DgradArgs& a, hipStream_t st) {
     const size_t lds = RING_BYTES + (size_t)a.side_floats * 4;
     MN_CHECK_ARG(lds <= 160 * 1024, "LDS budget exceeded: %zu bytes", lds);
     auto kern = mlp_dgrad_kernel<W>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        MN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    static LdsOptIn opt_in = {};
+    if (int rc = ensure_lds_opt_in(opt_in, (const void*)kern)) return rc;
     const long long n_wg = (a.n_wtiles + 3) / 4;
     const int grid = (int)(n_wg < (long long)num_cus_t() ? n_wg : (long long)num_cus_t());
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);

@@ -444,13 +444,18 @@ __global__ __launch_bounds__(256) void fine_z_kernel(const float* __restrict__ z
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    // rank sort (values only matter, ties broken by position): rank = #smaller + #equal-before
+    // rank sort (values only matter, ties broken by position): rank = #smaller + #equal-before.  NaN depths (a diverged
+    // network: NaN weights -> NaN samples) compare as +inf, so they rank LAST in position order like torch.sort places them
+    // (nerf_process.py:67) and every output slot is written exactly once -- with plain float compares several NaNs would share
+    // a rank and leave slots of z_f (torch.empty) uninitialised.
     for (int e = lane; e < St; e += 64) {
         const float v = all[e];
+        const float vk = (v != v) ? __builtin_inff() : v;
         int rank = 0;
         for (int k = 0; k < St; ++k) {
             const float o = all[k];
-            rank += (o < v || (o == v && k < e)) ? 1 : 0;
+            const float ok = (o != o) ? __builtin_inff() : o;
+            rank += (ok < vk || (ok == vk && k < e)) ? 1 : 0;
         }
         z_f[ray * St + rank] = v;
     }
@@ -459,6 +464,7 @@ __global__ __launch_bounds__(256) void fine_z_kernel(const float* __restrict__ z
 // ------------------------------------------------------------------------------------------------
 // host entry points (called from api.cpp)
 // ------------------------------------------------------------------------------------------------
+constexpr int MAX_LDS_FLOATS_PER_RAY = 64 * 1024 / 4 / 4;      // 4 rays per block share 64 KB: 4096 floats per ray
 static inline unsigned blocks_for(long long n, int per_block) { return (unsigned)((n + per_block - 1) / per_block); }
 
 int stage_make_o_d(int W, int H, const float k4[4], const float pose12[12], int row0, int n_rows, float* o, float* d,
@@ -572,7 +578,8 @@ int stage_composite_backward(const float* raw, const float* z, const float* rays
 
 int stage_sample_pdf(const float* bins, const float* weights, int64_t n, int B, int N, int det, const float* u, float* out,
                      hipStream_t st) {
-    MN_CHECK_ARG(n >= 0 && B >= 2 && B <= 4096 && N >= 1, "bad sizes (B=%d N=%d)", B, N);
+    // 4 rays per block, 2B floats each, within the 64 KB of dynamic LDS a launch gets without opting in
+    MN_CHECK_ARG(n >= 0 && B >= 2 && B <= MAX_LDS_FLOATS_PER_RAY / 2 && N >= 1, "bad sizes (B=%d N=%d; at most %d bins)", B, N, MAX_LDS_FLOATS_PER_RAY / 2);
     if (n == 0) return MI_NERF_OK;
     MN_CHECK_ARG(bins && weights && out && (det || u), "NULL pointer");
     hipLaunchKernelGGL(sample_pdf_kernel, dim3(blocks_for(n, 4)), dim3(256), (size_t)4 * 2 * B * sizeof(float), st, bins, weights,
@@ -583,7 +590,9 @@ int stage_sample_pdf(const float* bins, const float* weights, int64_t n, int B, 
 
 int stage_fine_z(const float* z_c, const float* w_c, int64_t n, int Sc, int Nf, int det, const float* u, float* z_f, float* z_samp,
                  hipStream_t st) {
-    MN_CHECK_ARG(n >= 0 && Sc >= 3 && Nf >= 1 && Sc + Nf <= 4096, "bad sizes (Sc=%d Nf=%d)", Sc, Nf);
+    // 4 rays per block, 2(Sc-1) + Sc + Nf floats each, within the 64 KB of dynamic LDS a launch gets without opting in
+    MN_CHECK_ARG(n >= 0 && Sc >= 3 && Nf >= 1 && 2 * (Sc - 1) + Sc + Nf <= MAX_LDS_FLOATS_PER_RAY, "bad sizes (Sc=%d Nf=%d: 3*Sc + Nf - 2 must not exceed %d)",
+                 Sc, Nf, MAX_LDS_FLOATS_PER_RAY);
     if (n == 0) return MI_NERF_OK;
     MN_CHECK_ARG(z_c && w_c && z_f && (det || u), "NULL pointer");
     const size_t lds = (size_t)4 * (2 * (Sc - 1) + Sc + Nf) * sizeof(float);

@@ -63,10 +63,12 @@ def write_png(path: str, img: np.ndarray) -> None:
                 + chunk(b"IDAT", zlib.compress(rows, 6)) + chunk(b"IEND", b""))
 
 
-def load_checkpoint(path: str, model: Optional[torch.nn.Module] = None) -> Dict:
+def load_checkpoint(path: str, model: Optional[torch.nn.Module] = None, *, allow_pickle: bool = False) -> Dict:
     """torch.load of a reference checkpoint ({'idx', 'model_state_dict', 'optimizer_state_dict'}, train.py:105-114);
-    loads ``model_state_dict`` into ``model`` when given (test.py:20-21)."""
-    ck = torch.load(path, map_location="cpu", weights_only=False)
+    loads ``model_state_dict`` into ``model`` when given (test.py:20-21).  The format holds tensors and plain containers only,
+    so it is read with ``weights_only=True``; ``allow_pickle=True`` opts in to the unrestricted (code-executing) unpickler
+    for checkpoints that need it."""
+    ck = torch.load(path, map_location="cpu", weights_only=not allow_pickle)
     if "model_state_dict" not in ck:
         raise MiNerfError(f"{path}: no 'model_state_dict' (keys: {sorted(ck)[:8]})")
     if model is not None:

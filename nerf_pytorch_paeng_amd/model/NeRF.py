@@ -3,7 +3,7 @@
 Same constructor arguments, same sub-module and parameter names (so ``load_state_dict`` accepts the
 reference's checkpoints, train.py:105-114), same ``forward(x, is_fine)`` contract.  The forward pass
 is the hand-written MFMA kernel (``mi_nerf_mlp_embedded``): parameters are packed into the kernel's
-streaming layout on first use and re-packed only when they change.  Under ``torch.no_grad()`` (test.py:36,140) ``forward`` is
+streaming layout from their current values on every call (two gather launches).  Under ``torch.no_grad()`` (test.py:36,140) ``forward`` is
 the inference kernel; with gradients enabled it is differentiable w.r.t. the selected network's parameters (hand-written
 backward, train_path.py), so a caller that keeps the reference's own ``nerf_process.py`` and swaps only the model still trains.
 """
@@ -33,7 +33,14 @@ class NeRFModule(nn.Module):
         self.linear_color = nn.Linear(W // 2, 3)
 
     def forward(self, x):
-        raise MiNerfError("call the parent NeRF module (model(x, is_fine)); the packed kernel needs both nets' context")
+        """x [n, input_ch + input_ch_d] -> [n, 4], like the reference's sub-module (model/NeRF.py:33-52; its NeRF.forward merely
+        dispatches to ``model_coarse`` / ``model_fine``, NeRF.py:75-78).  Routed through the parent NeRF, which owns the packed
+        blobs of both networks."""
+        parent = getattr(self, "_parent", None)
+        parent = parent() if parent is not None else None
+        if parent is None:
+            raise MiNerfError("this NeRFModule is not part of a NeRF (model/NeRF.py:58-59): construct it through NeRF(...)")
+        return parent(x, is_fine=parent.model_fine is self)
 
 
 class NeRF(nn.Module):
@@ -41,6 +48,10 @@ class NeRF(nn.Module):
         super().__init__()
         self.model_coarse = NeRFModule(D, W, input_ch, input_ch_d, skips)
         self.model_fine = NeRFModule(D, W, input_ch, input_ch_d, skips)
+        # weak back references (not sub-modules, not state): model.model_coarse(x) works like the reference's
+        import weakref
+        object.__setattr__(self.model_coarse, "_parent", weakref.ref(self))
+        object.__setattr__(self.model_fine, "_parent", weakref.ref(self))
         self.apply(self._init_weights)                                   # NeRF.py:60,63-65
         self.gt_intrinsic, self.gt_extrinsic = gt_camera_param if gt_camera_param is not None else (None, None)
 

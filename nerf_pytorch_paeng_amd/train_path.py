@@ -173,6 +173,9 @@ def render_train(rays: torch.Tensor, model: torch.nn.Module, opts, *, t_rand=Non
     """Differentiable ``render_rays`` (nerf_process.py:185-216) for one slab of rays [n, 6]."""
     st = _state_for(model)
     dev = st.device
+    if isinstance(rays, torch.Tensor) and rays.requires_grad:
+        raise MiNerfError("rays require grad: the training path differentiates w.r.t. the MLP parameters only (the reference trains "
+                          "nothing else, main.py:79-80); detach the rays, or a gradient would be dropped silently")
     rays = as_f32_dev(rays, dev)
     n = rays.shape[0]
     Sc, Nf = int(opts.N_samples_c), int(opts.N_samples_f)
@@ -199,8 +202,13 @@ class RenderModule(torch.nn.Module):
     The reference trains on one GPU (main.py:166-170).  For data-parallel training wrap THIS module, not the NeRF, in
     ``torch.nn.parallel.DistributedDataParallel``: DDP needs the forward to go through the wrapper, and the NeRF's own
     ``forward(x, is_fine)`` is the embedded-input call of model/NeRF.py:70-78.  The hand-written backward returns ordinary
-    parameter gradients, so DDP's bucketed all-reduce (RCCL over xGMI with backend "nccl") overlaps with it as usual: the
-    coarse network's gradients are reduced while the fine network's backward is still running."""
+    parameter gradients and DDP all-reduces them in buckets (RCCL over xGMI with backend "nccl").  Both networks' gradients
+    come out of ONE autograd node, so they become ready together at the end of the backward: the all-reduce of the 4.8 MB of
+    gradients (~0.1 ms on xGMI) follows the 20 ms backward, it does not overlap with it.
+
+    Jitter: without explicit ``t_rand`` / ``u`` / ``ray_offset`` the generator is keyed on (seed, ray_offset + local ray index);
+    every rank would then draw the SAME jitter for its local ray i.  ``forward`` therefore offsets the key by
+    ``rank * 2^24`` rays unless the caller passes ``ray_offset``."""
 
     def __init__(self, model: torch.nn.Module, posenc, opts):
         super().__init__()
@@ -208,4 +216,8 @@ class RenderModule(torch.nn.Module):
 
     def forward(self, rays_o, rays_d, H, W, K, **kw):
         from . import nerf_process as NP
+        if "ray_offset" not in kw and "t_rand" not in kw:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                kw["ray_offset"] = dist.get_rank() << 24
         return NP.batchify_rays_and_render_by_chunk(rays_o, rays_d, self.model, self.posenc, H, W, K, self.opts, **kw)

@@ -71,7 +71,8 @@ class PackedNeRF:
         return self
 
     def bf16(self) -> Tuple[torch.Tensor, torch.Tensor]:
-        """bf16-stream blobs for the bf16 MFMA variant (packed lazily)."""
+        """bf16-stream blobs for the bf16 MFMA variant (packed lazily, on the host; for an nn.Module source from the parameter
+        values at the time this PackedNeRF was made -- packed_for() makes a new one per call)."""
         if self._bf16 is None:
             src = self._sd_source() if self._sd_source is not None else None
             if self._sd is None and src is not None:
@@ -87,33 +88,26 @@ class PackedNeRF:
 
 
 # ---------------------------------------------------------------------------------------------------
-# cache for nn.Module models (ours or the reference's): repack only when a parameter changed
+# nn.Module models (ours or the reference's): re-packed from the LIVE parameters on every call
 # ---------------------------------------------------------------------------------------------------
-_cache: "weakref.WeakKeyDictionary[torch.nn.Module, Tuple[tuple, PackedNeRF]]" = weakref.WeakKeyDictionary()
-
-
-def _fingerprint(model: torch.nn.Module) -> tuple:
-    return tuple((p.data_ptr(), p._version, str(p.device)) for p in model.parameters())
-
-
+# An earlier version cached the packed blobs keyed on (data_ptr, _version, device) of every parameter.  Writes through ``p.data``
+# (EMA updates, hand-written optimisers, some weight loaders) change the values without bumping ``_version`` or moving the storage,
+# so the cache could serve stale weights to the no-grad path while the training path (which always re-packs) used the new ones.
+# The device-side re-pack is one ``torch.cat`` of the 48 parameter tensors and two gather launches per network (tens of
+# microseconds against the 8 ms of a 4096-ray batch, once per ``render_rays`` / ``batchify`` call), so it simply runs every time.
+# Callers that render many batches from frozen weights pass a ``PackedNeRF`` (``PackedNeRF.from_state_dict`` or ``packed_for`` once).
 def packed_for(model, device=None) -> PackedNeRF:
-    """PackedNeRF for ``model``: a PackedNeRF passes through; an nn.Module with the reference's
-    ``model_coarse`` / ``model_fine`` layout is packed once and cached until its parameters change."""
+    """PackedNeRF for ``model``: a PackedNeRF passes through; an nn.Module with the reference's ``model_coarse`` /
+    ``model_fine`` layout is packed from its current parameter values (never cached)."""
     if isinstance(model, PackedNeRF):
         return model
     if not isinstance(model, torch.nn.Module) or not hasattr(model, "model_coarse") or not hasattr(model, "model_fine"):
         raise MiNerfError("model must be a PackedNeRF or an nn.Module with model_coarse / model_fine (model/NeRF.py:58-59)")
-    fp = _fingerprint(model)
-    hit = _cache.get(model)
-    if hit is not None and hit[0] == fp and (device is None or hit[1].device == torch.device(device)):
-        return hit[1]
     if device is None:
         device = next(model.parameters()).device
     if torch.device(device).type != "cuda":
         raise MiNerfError(f"model lives on {device}: the MI355X path needs a HIP device (no CPU fallback)")
-    packed = _pack_module_on_device(model, torch.device(device))
-    _cache[model] = (fp, packed)
-    return packed
+    return _pack_module_on_device(model, torch.device(device))
 
 
 # gather maps per network shape (built once by the host packer, kept on the device)

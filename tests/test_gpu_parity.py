@@ -134,7 +134,7 @@ def test_sample_pdf_F4(golden):
     for got, key in ((s_det, "samples_det"), (s_rnd, "samples_rand")):
         frac = _flip_fraction(got, T(g[key]), 5e-6)
         print(f'sample_pdf {key}: samples off by >5e-6: {frac:.2e}')
-        assert frac <= 6e-3, (key, frac)
+        assert frac <= 5e-3, (key, frac)                 # observed 2.4e-3 .. 2.9e-3
         assert float((got.cpu() - T(g[key])).abs().median()) <= 5e-7
     kat = NP.sample_pdf(torch.linspace(2, 6, 5)[None].to(DEV), torch.tensor([[0.1, 0.0, 0.6, 0.3]], device=DEV), 6, det=True, opts=opts)
     close(kat, g["kat_samples"], 2e-6)
@@ -143,7 +143,8 @@ def test_sample_pdf_F4(golden):
     zf, zs = ops.fine_z(g2d(g["z_coarse"]), wc, 128, False, u, want_samples=True)
     assert torch.all(zf[:, 1:] >= zf[:, :-1])
     assert torch.equal(torch.sort(torch.cat([g2d(g["z_coarse"]), zs], -1), -1)[0], zf)       # exact multiset, sorted
-    assert _flip_fraction(zf, T(g["z_fine"]), 5e-6) <= 8e-3
+    ff = _flip_fraction(zf, T(g["z_fine"]), 5e-6)
+    assert ff <= 5e-3, ff                                # observed 2.7e-3
 
 
 def test_posenc_embed_F5(golden):
@@ -194,6 +195,43 @@ def test_mlp_repack_on_weight_change():
         model.model_coarse.linear_color.bias.add_(1.0)
         y1 = model(x)
     close(y1[:, :3] - y0[:, :3], np.ones((64, 3), np.float32), 1e-5)
+
+
+def test_submodules_are_callable_like_the_reference():
+    """model.model_coarse(x) / model.model_fine(x) (model/NeRF.py:33-52: the reference's NeRF.forward only dispatches to them)."""
+    sd = synthetic.make_state_dict(3, 4, 128)
+    model = NeRF(4, 128, 63, 27)
+    model.load_state_dict({k: T(v) for k, v in sd.items()})
+    model.to(DEV)
+    x = torch.rand(70, 90, device=DEV)
+    with torch.no_grad():
+        assert torch.equal(model.model_coarse(x), model(x)) and torch.equal(model.model_fine(x), model(x, is_fine=True))
+    assert "_parent" not in model.state_dict() and len(list(model.model_coarse.children())) == 5      # no new state, no cycle of sub-modules
+    y = model.model_fine(x)                                                                            # grad mode: differentiable like model(x, True)
+    y.sum().backward()
+    assert model.model_fine.linear_color.weight.grad is not None and model.model_coarse.linear_color.weight.grad is None
+
+
+def test_weights_written_through_data_are_seen(lego_rays):
+    """Writes through ``p.data`` (EMA, hand-written optimisers, weight loaders) bump no version counter: the inference path must
+    still render with the new values -- packed_for() re-packs nn.Module models from the live parameters on every call."""
+    sd = synthetic.make_state_dict(3, 4, 128)
+    model = NeRF(4, 128, 63, 27)
+    model.load_state_dict({k: T(v) for k, v in sd.items()})
+    model.to(DEV)
+    opts = make_opts(N_samples_c=16, N_samples_f=16)
+    rays = lego_rays[:32].contiguous()
+    with torch.no_grad():
+        a = NP.render_rays(rays, model, None, opts, seed=3)
+        v0 = model.model_fine.linear_color.bias._version
+        model.model_fine.linear_color.bias.data.mul_(0.0).add_(5.0)            # sigmoid(5 + ...) ~ 1: a visibly different image
+        model.model_coarse.linear_x[0].weight.data.copy_(torch.zeros_like(model.model_coarse.linear_x[0].weight))
+        assert model.model_fine.linear_color.bias._version == v0               # the old cache key could not see this
+        b = NP.render_rays(rays, model, None, opts, seed=3)
+        fresh = weights.PackedNeRF.from_state_dict({k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}, DEV)
+        c = NP.render_rays(rays, fresh, None, opts, seed=3)
+    assert not torch.equal(a["rgb_f"], b["rgb_f"]) and not torch.equal(a["rgb_c"], b["rgb_c"])
+    assert torch.equal(b["rgb_f"], c["rgb_f"]) and torch.equal(b["rgb_c"], c["rgb_c"])
 
 
 @pytest.mark.parametrize("S", [64, 192, 40])
@@ -305,7 +343,7 @@ def test_render_rays_F8(golden, tag):
     z_f = ops.fine_z(z_c_ref, g2d(g[f"{tag}_weights_c"]), Nf, det, u)
     moved = float(((z_f - z_f_ref).abs() > 5e-6).float().mean())
     print(f"{tag}: staged fine depths off by >5e-6: {moved:.2e}")
-    assert moved <= 3e-3
+    assert moved <= 5e-3, moved                          # observed 2.4e-4 .. 2.7e-3 (64-ray fixtures: one flip = 8e-5)
     # ---- fine network + composite on the reference's depths
     raw_f = ops.mlp_rays(packed.net, packed.fine, rays, z_f_ref)
     close(raw_f, g[f"{tag}_raw_f"], 1e-4, 1e-4, what="raw_f")
@@ -319,9 +357,9 @@ def test_render_rays_F8(golden, tag):
     mse = float(((out["rgb_f"].cpu() - T(g[f"{tag}_rgb_f"])) ** 2).mean())
     print(f"{tag}: end-to-end fine depths moved >1e-4: {float((dz > 1e-4).float().mean()):.2e}; rays with rgb_f off by >1e-4: "
           f"{float(ray_bad):.3f}; rgb_f max err {err(out['rgb_f'], g[f'{tag}_rgb_f']):.2e}; PSNR vs reference {R.mse2psnr(mse):.1f} dB")
-    assert float((dz > 1e-4).float().mean()) <= 5e-3
-    assert float(ray_bad) <= 0.05
-    assert R.mse2psnr(mse) > 60.0                                               # >> the 0.05 dB PSNR bar
+    assert float((dz > 1e-4).float().mean()) <= 3e-3, float((dz > 1e-4).float().mean())     # observed <= 9.8e-4
+    assert float(ray_bad) <= 0.016, float(ray_bad)                              # observed 0.000: at most ONE of the 64 rays
+    assert R.mse2psnr(mse) > 100.0, R.mse2psnr(mse)                             # observed 117 .. 119 dB (the bar: PSNR within 0.05 dB)
 
 
 @pytest.mark.parametrize("tag", ["blender", "llff"])
@@ -341,7 +379,7 @@ def test_batchify_F9(golden, tag):
     close(rc, g[f"{tag}_rgb_c"], 1e-4, what="rgb_c"); close(dc, g[f"{tag}_disp_c"], 1e-4, 1e-4)
     bad = ((rf.cpu() - T(g[f"{tag}_rgb_f"])).abs().max(-1)[0] > 1e-4).float().mean()
     print(f"{tag}: rays with rgb_f off by >1e-4: {float(bad):.3f}")
-    assert float(bad) <= 0.05
+    assert float(bad) <= 0.01, float(bad)                # observed 0.000 (256 rays)
     # K as a float64 device tensor (train.py:18) behaves the same
     rc2, *_ = NP.batchify_rays_and_render_by_chunk(o, d, model, posenc, 16, 16, torch.from_numpy(K).to(DEV), opts, t_rand=t_all, u=u_all)
     assert torch.equal(rc2, rc)
@@ -379,7 +417,7 @@ def test_full_size_properties(packed_big, lego_rays):
     ref = R.render_rays(lego_rays[idx].cpu(), sd, R.PathConfig(), a["_t_rand"][idx].cpu(), a["_u"][idx].cpu())
     close(a["rgb_c"][idx], ref["rgb_c"], 1e-4)
     bad = ((a["rgb_f"][idx].cpu() - ref["rgb_f"]).abs().max(-1)[0] > 1e-4).float().mean()
-    assert float(bad) <= 0.08
+    assert float(bad) <= 0.016, float(bad)               # 64-ray subset; all 4096 rays: test_config2_all_rays_vs_oracle
 
 
 def test_empty_and_tiny_batches(packed_big, lego_rays):
@@ -423,7 +461,7 @@ def test_bf16_mlp_vs_fp32(packed_big, lego_rays):
     rel = float(d.mean()) / scale
     print(f"bf16 vs fp32 raw: mean |diff| {float(d.mean()):.3e} (mean |raw| {scale:.3f}, relative {rel:.2e}), max {float(d.max()):.3e}")
     assert torch.isfinite(raw16).all()
-    assert rel < 2e-2 and float(d.max()) < 0.5          # ~8 mantissa bits per product, averaged over 256-term sums
+    assert rel < 1e-2 and float(d.max()) < 0.2, (rel, float(d.max()))      # observed 6.5e-3 / 6.6e-2: ~8 mantissa bits per product over 256-term sums
 
 
 def test_bf16_render_psnr(packed_big, lego_rays):
@@ -433,7 +471,7 @@ def test_bf16_render_psnr(packed_big, lego_rays):
     for k in ("rgb_c", "rgb_f"):
         mse = float(((a[k] - b[k]) ** 2).mean())
         print(f"bf16 vs fp32 {k}: PSNR {R.mse2psnr(mse):.1f} dB, max |diff| {float((a[k] - b[k]).abs().max()):.3e}")
-        assert torch.isfinite(b[k]).all() and R.mse2psnr(mse) > 30.0
+        assert torch.isfinite(b[k]).all() and R.mse2psnr(mse) > (70.0 if k == "rgb_c" else 50.0), (k, R.mse2psnr(mse))      # observed 74.6 / 53.9 dB
     # odd sizes and determinism
     c = NP.render_rays(lego_rays[:7].contiguous(), packed_big, None, opts, t_rand=a["_t_rand"][:7], u=a["_u"][:7], bf16=True)
     assert torch.equal(c["rgb_f"], b["rgb_f"][:7])
@@ -512,3 +550,45 @@ def test_bf16_through_module_model(lego_rays):
         c = NP.render_rays(rays, model, None, opts, seed=3)
         d = NP.render_rays(rays, packed, None, opts, seed=3)
     assert torch.equal(a["rgb_f"], b["rgb_f"]) and torch.equal(c["rgb_f"], d["rgb_f"])
+
+
+def test_bf16_mlp_vs_bf16_oracle(packed_big, lego_rays):
+    """The bf16 kernel against the oracle with the kernel's rounding points (R.mlp_forward_bf16: bf16 weights, bf16 gamma(x), bf16
+    activations, fp32 accumulation) -- the check that a systematic packing / ordering error cannot pass: such an error moves
+    outputs by O(1e-1) of their scale, fp32 summation order and round-to-bf16 boundary flips move them by O(1e-3)."""
+    sd = synthetic.make_state_dict(0, 8, 256)
+    for n, S in ((64, 192), (33, 100), (5, 64)):
+        rays = lego_rays[:n].contiguous()
+        z = torch.sort(T(R.counter_uniform(2, 0, 0, n, S)) * 4 + 2, -1)[0]
+        raw16 = ops.mlp_rays(packed_big.net, packed_big.bf16()[1], rays, z.to(DEV), bf16=True).cpu()
+        ref = R.mlp_forward_bf16(sd, "model_fine.", R.embed(rays.cpu(), z, 10, 4), 8, 63, 27).reshape(n, S, 4)
+        e = (raw16 - ref).abs()
+        rel = [float(e[..., c].mean() / ref[..., c].abs().mean()) for c in range(4)]
+        print(f"bf16 kernel vs bf16 oracle n={n} S={S}: mean |err| / mean |ref| per channel {[f'{v:.1e}' for v in rel]}, max |err| {float(e.max()):.3e}")
+        assert torch.isfinite(raw16).all()
+        assert max(rel) < 2e-3, rel                      # observed 2e-4 .. 5e-4
+        assert float(e.max()) < 0.2, float(e.max())      # a flipped bf16 rounding of one activation, amplified by the x20 density head
+
+
+def test_config2_all_rays_vs_oracle(packed_big, lego_rays):
+    """BASELINE config #2 at full size, EVERY ray against the CPU oracle: coarse colours and disparities directly; fine outputs
+    with the depths pinned to the ones the HIP path sampled (sample_pdf's branch flips are counted separately below)."""
+    opts = make_opts()
+    a = NP.render_rays(lego_rays, packed_big, None, opts, seed=11, return_intermediates=True)
+    sd = synthetic.make_state_dict(0, 8, 256)
+    torch.set_num_threads(max(1, min(16, len(__import__("os").sched_getaffinity(0)))))
+    rc, tr, uu = lego_rays.cpu(), a["_t_rand"].cpu(), a["_u"].cpu()
+    with torch.no_grad():
+        ref = R.render_rays(rc, sd, R.PathConfig(), tr, uu)
+        pin = R.render_rays(rc, sd, R.PathConfig(), tr, uu, z_fine_override=a["_z_f"].cpu())
+    e_c = float((a["rgb_c"].cpu() - ref["rgb_c"]).abs().max())
+    e_dc = float((a["disp_c"].cpu() - ref["disp_c"]).abs().max())
+    e_f = float((a["rgb_f"].cpu() - pin["rgb_f"]).abs().max())
+    e_df = float(((a["disp_f"].cpu() - pin["disp_f"]).abs() / pin["disp_f"].abs().clamp_min(1e-3)).max())
+    bad = float(((a["rgb_f"].cpu() - ref["rgb_f"]).abs().max(-1)[0] > 1e-4).float().mean())
+    mse = float(((a["rgb_f"].cpu() - ref["rgb_f"]) ** 2).mean())
+    print(f"config #2, 4096 rays vs oracle: rgb_c max err {e_c:.2e}, disp_c {e_dc:.2e}; pinned rgb_f {e_f:.2e}, disp_f rel {e_df:.2e}; "
+          f"un-pinned rays off by >1e-4: {bad:.4f}, PSNR {R.mse2psnr(mse):.1f} dB")
+    assert e_c <= 2e-5 and e_dc <= 2e-4, (e_c, e_dc)      # north-star bar 1e-4; observed 2e-6 / 3e-5
+    assert e_f <= 2e-5 and e_df <= 2e-4, (e_f, e_df)
+    assert bad <= 0.01 and R.mse2psnr(mse) > 90.0, (bad, R.mse2psnr(mse))

@@ -202,3 +202,39 @@ def test_bf16_blob_emulation_matches_bf16_oracle(D, skip):
     x = torch.cat([R.posenc(torch.from_numpy(p).double(), 10), torch.from_numpy(g)[None].expand(32, 27)], -1)
     ref = R.mlp_forward_bf16(sd, "model_coarse.", x, D, 63, 27, skips=(skip,) if skip >= 0 else (), dtype=torch.float64).numpy()
     np.testing.assert_allclose(out, ref, atol=1e-9, rtol=1e-9)
+
+
+def test_bf16_kernel_owns_m0_and_the_agpr_file():
+    """mlp_bf16.hip sets M0 without saving it and addresses the whole AGPR file by explicit register numbers: both are only
+    sound while hipcc itself never touches M0 / an AGPR in that kernel.  Disassemble the object and check."""
+    import os
+    import re
+    import subprocess
+    from nerf_pytorch_paeng_amd import build
+    obj = os.path.join(build.CSRC, "build", "mlp_bf16.hip.o")
+    assert os.path.exists(obj), "build the library first"
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not found")
+    import shutil
+    import tempfile
+    work = tempfile.mkdtemp()
+    try:
+        local = os.path.join(work, "k.o")
+        shutil.copy(obj, local)
+        subprocess.run([objdump, "--offloading", local], check=True, capture_output=True, cwd=work)      # extracts k.o.0.hipv4-...-gfx950
+        dev = [f for f in os.listdir(work) if f.endswith("gfx950")]
+        assert len(dev) == 1, os.listdir(work)
+        asm = subprocess.run([objdump, "-d", os.path.join(work, dev[0])], check=True, capture_output=True, text=True).stdout
+    finally:
+        shutil.rmtree(work)
+    lines = [l.split("//")[0].strip() for l in asm.splitlines()]
+    mfma = [l for l in lines if l.startswith("v_mfma_f32_32x32x16_bf16")]
+    assert len(mfma) > 2000
+    assert not any(l.startswith("v_accvgpr_read") for l in lines)                 # the compiler never moves data out of the file
+    assert not any(l.startswith("scratch_") for l in lines)                       # no spills
+    m0 = [l for l in lines if re.search(r"\bm0\b", l)]
+    assert m0 and all(re.fullmatch(r"s_mov_b32 m0, s\d+", l) for l in m0), m0[:5]  # only our "s_mov_b32 m0, sN"
+    for l in lines:                                                               # AGPRs appear only as MFMA B operands / accvgpr_write targets
+        if re.search(r"\ba\[?\d", l):
+            assert l.startswith("v_accvgpr_write_b32 a") or l.startswith("v_mfma_f32_32x32x16_bf16 v["), l

@@ -1,12 +1,13 @@
 """A/B timing of the fused MLP kernel: the shipped library against a variant built with
 `python -m nerf_pytorch_paeng_amd.build --variant TAG -D...`, alternating in ONE process on ONE box (box-to-box
-variance is ~0.5 %, more than most single changes):  python tools/ab_probe.py TAG [rounds] [bf16]"""
+variance is ~0.5 %, more than most single changes):  python tools/ab_probe.py TAG[,TAG2,...] [rounds] [bf16]"""
 import ctypes as C
 import os
 import sys
 
 import torch
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nerf_pytorch_paeng_amd import _lib, ops, synthetic, weights
 
 tag = sys.argv[1]
@@ -22,11 +23,12 @@ z = torch.sort(torch.rand(4096, 192, device=dev) * 4 + 2, -1)[0]
 raw = torch.empty(4096, 192, 4, device=dev)
 
 libs = {"shipped": _lib.lib()}
-h = C.CDLL(os.path.join(os.path.dirname(_lib.LIB_PATH), f"libmi_nerf_{tag}.so"))
-for name, (res, args) in _lib.SIGNATURES.items():
-    fn = getattr(h, name)
-    fn.restype, fn.argtypes = res, args
-libs[tag] = h
+for tg in tag.split(","):
+    h = C.CDLL(os.path.join(os.path.dirname(_lib.LIB_PATH), f"libmi_nerf_{tg}.so"))
+    for name, (res, args) in _lib.SIGNATURES.items():
+        fn = getattr(h, name)
+        fn.restype, fn.argtypes = res, args
+    libs[tg] = h
 
 
 def time(lib, iters=20):
