@@ -1,0 +1,22 @@
+#!/bin/bash
+# round-2 evidence run: PMC passes of the shipped fp32 inference kernel, the training kernels and the stand-alone wgrad product
+set -o pipefail
+export TMPDIR=/tmp
+O=gpurun_out/r2p
+mkdir -p $O
+B="python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --frames 0 --train-steps 0 --no-small-batch"
+# the rocpd databases are ~7 MB each and only 64 MiB travel back: summarise on the box, keep the JSON
+run() { tag=$1; shift; timeout -k 10 240 rocprofv3 "$@" > $O/$tag.log 2>&1; echo "$tag rc=$?"; python3 tools/rocpd_summary.py $O/$tag/r_results.db --last 3 > $O/$tag.json 2>>$O/$tag.log; rm -rf $O/$tag; tail -c 2000 $O/$tag.log > $O/$tag.log.tail; rm -f $O/$tag.log; }
+run fp32_stats --kernel-trace --stats -d $O/fp32_stats -o r -- $B
+run fp32_pmc1 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $O/fp32_pmc1 -o r -- $B
+run fp32_pmc2 --pmc FETCH_SIZE -d $O/fp32_pmc2 -o r -- $B
+run fp32_pmc3 --pmc WRITE_SIZE -d $O/fp32_pmc3 -o r -- $B
+run fp32_pmc4 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_SALU SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_INSTS_MFMA -d $O/fp32_pmc4 -o r -- $B
+T="python3 tools/train_probe.py 4096 4"
+run train_stats --kernel-trace --stats -d $O/train_stats -o r -- $T
+run train_pmc1 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA -d $O/train_pmc1 -o r -- $T
+run train_pmc2 --pmc FETCH_SIZE -d $O/train_pmc2 -o r -- $T
+run train_pmc3 --pmc WRITE_SIZE -d $O/train_pmc3 -o r -- $T
+W="python3 tools/wgrad_probe.py"
+run wgrad_pmc1 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA -d $O/wgrad_pmc1 -o r -- $W
+ls $O

@@ -3,6 +3,8 @@ import sys
 import time
 from types import SimpleNamespace
 
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 from nerf_pytorch_paeng_amd import nerf_process as NP, ops, synthetic

@@ -1,5 +1,7 @@
 """Time one weight-gradient product (256x256 over P points) at several P: python tools/wgrad_probe.py
 Separates the fixed cost (launch, accumulator write-out, slice reduction) from the steady-state MFMA rate."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 from nerf_pytorch_paeng_amd import ops
