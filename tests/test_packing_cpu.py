@@ -193,13 +193,13 @@ def test_bf16_blob_emulation_matches_bf16_oracle(D, skip):
     blob = ops.pack_module(sd, "model_coarse.", net, bf16=True).numpy()
     rs = np.random.RandomState(2)
     ray = rs.normal(size=6)
-    z = np.sort(rs.uniform(2, 6, 32))
-    p = (ray[:3, None] + ray[3:, None] * z[None, :]).T.astype(np.float32)           # [32, 3]
+    z = np.sort(rs.uniform(2, 6, 16))
+    p = (ray[:3, None] + ray[3:, None] * z[None, :]).T.astype(np.float32)           # [16, 3]: one MFMA point tile
     v = ray[3:] / np.linalg.norm(ray[3:])
     g = R.posenc(torch.from_numpy(v[None]), 4)[0].numpy()
     emu = EmuBf16(blob)
     out = emu.tile(p.astype(np.float64), g)
-    x = torch.cat([R.posenc(torch.from_numpy(p).double(), 10), torch.from_numpy(g)[None].expand(32, 27)], -1)
+    x = torch.cat([R.posenc(torch.from_numpy(p).double(), 10), torch.from_numpy(g)[None].expand(16, 27)], -1)
     ref = R.mlp_forward_bf16(sd, "model_coarse.", x, D, 63, 27, skips=(skip,) if skip >= 0 else (), dtype=torch.float64).numpy()
     np.testing.assert_allclose(out, ref, atol=1e-9, rtol=1e-9)
 
@@ -229,12 +229,12 @@ def test_bf16_kernel_owns_m0_and_the_agpr_file():
     finally:
         shutil.rmtree(work)
     lines = [l.split("//")[0].strip() for l in asm.splitlines()]
-    mfma = [l for l in lines if l.startswith("v_mfma_f32_32x32x16_bf16")]
-    assert len(mfma) > 2000
+    mfma = [l for l in lines if l.startswith("v_mfma_f32_16x16x32_bf16")]
+    assert len(mfma) > 4000
     assert not any(l.startswith("v_accvgpr_read") for l in lines)                 # the compiler never moves data out of the file
     assert not any(l.startswith("scratch_") for l in lines)                       # no spills
     m0 = [l for l in lines if re.search(r"\bm0\b", l)]
     assert m0 and all(re.fullmatch(r"s_mov_b32 m0, s\d+", l) for l in m0), m0[:5]  # only our "s_mov_b32 m0, sN"
     for l in lines:                                                               # AGPRs appear only as MFMA B operands / accvgpr_write targets
         if re.search(r"\ba\[?\d", l):
-            assert l.startswith("v_accvgpr_write_b32 a") or l.startswith("v_mfma_f32_32x32x16_bf16 v["), l
+            assert l.startswith("v_accvgpr_write_b32 a") or l.startswith("v_mfma_f32_16x16x32_bf16 v["), l
