@@ -18,8 +18,9 @@ the same run for N > 1; at N = 1 the two are the same measurement.
 
 Also on the line: the 800x800 frame time (rows sharded over the ranks, ONE all-gather of the output tiles
 over RCCL), `roofline` for the dominant kernel (the fine-network fused MLP launch, hipEvent-timed on its
-launch stream), `small_batch` (the same step at 256..2048 rays on one GPU: what a rank sees under strong
-scaling) and `cpu_baseline` (the CPU oracle timed on the host cores; rank 0, N = 1 only).
+launch stream), `bf16` (BASELINE config #5: the same step on the bf16 MFMA variant with its PSNR against the
+fp32 outputs of the same rays), `small_batch` (the same step at 256..2048 rays on one GPU: what a rank sees
+under strong scaling) and `cpu_baseline` (the CPU oracle timed on the host cores; rank 0, N = 1 only).
 
 Synthetic inputs: lego camera geometry, pose_spherical(0,-30,4), 4096 pixels from
 RandomState(0), Xavier(seed 0) weights with the density head x20, counter-based jitter seed 0.
@@ -66,6 +67,7 @@ def parse():
     ap.add_argument("--scaling", choices=["strong", "weak", "both"], default="both",
                     help="strong: the 4096-ray batch sharded over the GPUs (value); weak: 4096 rays per GPU (value_weak); both (default)")
     ap.add_argument("--no-small-batch", action="store_true", help="skip the 256..2048-ray legs (N = 1)")
+    ap.add_argument("--no-bf16-leg", action="store_true", help="skip the bf16 leg (BASELINE config #5) of the default fp32 run")
     return ap.parse_args()
 
 
@@ -249,6 +251,46 @@ def worker(args) -> None:
         roofline["peak_is"] = "dense bf16 MFMA"
         roofline["frac_of_f32_mfma_peak"] = round(achieved / PEAK_F32_MFMA_TFLOPS, 4)
 
+    # ---- BASELINE config #5 on the same shard: the bf16 MFMA variant, timed like the headline and held against the fp32 outputs ----
+    bf16_leg = None
+    if not args.bf16 and not args.no_bf16_leg:
+        cfg16 = ops.render_cfg(opts.near, opts.far, SC, NF, False, True)
+        blobs16 = packed.bf16()
+        out16 = tuple(torch.empty_like(t) for t in main.out)
+
+        def step16():
+            ops.render_rays(packed.net, blobs16[0], blobs16[1], cfg16, main.rays, main.t_rand, main.u, workspace=main.ws, out=out16)
+
+        step(main)                                           # fp32 outputs of this shard as the yardstick (same rays, same jitter)
+        ref32 = tuple(t.clone() for t in main.out)
+        for _ in range(args.warmup):
+            step16()
+        torch.cuda.synchronize(dev)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step16()
+        torch.cuda.synchronize(dev)
+        barrier()
+        el16 = max_over_ranks(time.perf_counter() - t0)
+        zf16 = ops.workspace_views(cfg16, main.n, main.ws)["z_f"].clone()
+        raw16 = torch.empty(main.n, SC + NF, 4, device=dev)
+        ops.time_mlp_rays(packed.net, blobs16[1], main.rays, zf16, raw16, 2, True)
+        k16 = ops.time_mlp_rays(packed.net, blobs16[1], main.rays, zf16, raw16, iters, True)
+
+        def psnr(x, y):
+            return float(-10.0 * torch.log10(torch.mean((x - y) ** 2).clamp_min(1e-20)))
+
+        n_total = N_RAYS if headline_strong else world * N_RAYS
+        bf16_leg = {"what": "BASELINE config #5: the same step with bf16 weights / activations on v_mfma_f32_16x16x32_bf16 (fp32 accumulate), this run's shard and jitter",
+                    "rays_per_s": round(n_total * args.steps / el16, 1), "ms_per_step": round(1e3 * el16 / args.steps, 4),
+                    "fine_kernel_ms": round(k16, 4),
+                    "fine_kernel_TFLOPs": round(k_flop / (k16 * 1e-3) / 1e12, 1),
+                    "fine_kernel_frac_of_bf16_peak": round(k_flop / (k16 * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
+                    "psnr_rgb_c_vs_fp32_dB": round(psnr(out16[0], ref32[0]), 2), "psnr_rgb_f_vs_fp32_dB": round(psnr(out16[2], ref32[2]), 2),
+                    "max_abs_rgb_f_diff": round(float((out16[2] - ref32[2]).abs().max()), 5)}
+        del raw16, zf16
+
     # ---- the same step at small batches (one GPU): what a rank runs under strong scaling ---------------------------
     small = None
     if world == 1 and not args.no_small_batch:
@@ -416,6 +458,8 @@ def worker(args) -> None:
         }
         if not args.bf16:
             line["frac_of_f32_mfma_roofline_end_to_end"] = line["frac_of_roofline_end_to_end"]
+        if bf16_leg is not None:
+            line["bf16"] = bf16_leg
         if small is not None:
             line["small_batch"] = small
         if train is not None:

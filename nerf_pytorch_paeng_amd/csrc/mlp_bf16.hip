@@ -422,7 +422,8 @@ void mlp_bf16_kernel(const MlpArgsB a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 15, q4 = lane >> 4;               // point of a 16-point tile; lane quarter
     float* scratch = side + a.side_floats + wave * (2 * (W / 2));      // per wave, per 32-sample tile: hoisted direction bias
-    char* pe_lds = (char*)(side + a.side_floats + 4 * 2 * (W / 2)) + wave * (NP * KPE * QUAD_BYTES) + lane * 16;   // parked gamma(x) fragments
+    char* pe_wave = (char*)(side + a.side_floats + 4 * 2 * (W / 2)) + wave * (NP * KPE * QUAD_BYTES);   // this wave's parked gamma(x) fragments
+    char* pe_lds = pe_wave + lane * 16;
     for (unsigned i = tid * 4; i < a.side_floats; i += 256 * 4) *(f32x4*)(side + i) = *(const f32x4*)(a.side + i);
 
     BRing ring;
@@ -453,7 +454,11 @@ void mlp_bf16_kernel(const MlpArgsB a) {
         if (a.ppr) { const unsigned blk = it / a.ppr; return (blk * NW + wid) * a.ppr + (it - blk * a.ppr); }
         return it * NW + wid;
     };
-    unsigned n_tile[2];  float nx_r[2][6], nx_z[NP];
+    // gamma(x) is computed ONCE per point: lane (q4, col) owns point `col` of point tile q4 (32-sample tile q4 >> 1, half q4 & 1),
+    // encodes it and writes its fragments' dwords where the other lane quarters read them (the fragments are parked in LDS for the
+    // skip layer anyway).  Each lane therefore loads one depth; the rays of both 32-sample tiles are loaded by every lane (the
+    // hoisted view-direction term is computed per tile by the whole wave).
+    unsigned n_tile[2];  float nx_r[2][6], nx_z;
     auto load_inputs = [&](unsigned it) __attribute__((always_inline)) {
         const unsigned pr = pair_of(it);
 #pragma unroll
@@ -465,10 +470,9 @@ void mlp_bf16_kernel(const MlpArgsB a) {
             const float* rp = a.rays + (size_t)ray * 6;
 #pragma unroll
             for (int e = 0; e < 6; ++e) nx_r[tl][e] = rp[e];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int sample = (int)chunk * 32 + 16 * h + col;
-                nx_z[2 * tl + h] = a.z[(size_t)ray * a.S + (sample < a.S ? sample : a.S - 1)];
+            if (tl == (q4 >> 1)) {
+                const int sample = (int)chunk * 32 + 16 * (q4 & 1) + col;
+                nx_z = a.z[(size_t)ray * a.S + (sample < a.S ? sample : a.S - 1)];
             }
         }
     };
@@ -524,7 +528,8 @@ void mlp_bf16_kernel(const MlpArgsB a) {
     for (unsigned it = 0; it < a.n_iter; ++it) {
         // ---- prologue: this pair's points, gamma(x) fragments, hoisted view-direction bias ------------------------------------
         unsigned tray[2]; bool valid[NP]; size_t out_idx[NP];
-        float in_o[2][3], in_d[2][3], in_z[NP];
+        float in_o[2][3], in_d[2][3];
+        const float in_z = nx_z;
 #pragma unroll
         for (int tl = 0; tl < 2; ++tl) {
             const bool active = n_tile[tl] < a.n_wtiles;
@@ -532,20 +537,20 @@ void mlp_bf16_kernel(const MlpArgsB a) {
             const unsigned ray = t / (unsigned)a.tpr, chunk = t - ray * (unsigned)a.tpr;
             tray[tl] = ray;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
+            for (int h = 0; h < 2; ++h) {                       // results of point tile p = 2 tl + h land on lane quarter 0, lane = point
                 const int sample = (int)chunk * 32 + 16 * h + col;
                 valid[2 * tl + h] = active && sample < a.S;
                 out_idx[2 * tl + h] = (size_t)ray * a.S + (sample < a.S ? sample : a.S - 1);
-                in_z[2 * tl + h] = nx_z[2 * tl + h];
             }
 #pragma unroll
             for (int e = 0; e < 3; ++e) { in_o[tl][e] = nx_r[tl][e]; in_d[tl][e] = nx_r[tl][3 + e]; }
         }
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            const int tl = p >> 1;
+        {
+            const bool t1 = (q4 >> 1) != 0;                     // this lane's point belongs to the second 32-sample tile
             // pts = rays_o + rays_d * z (nerf_process.py:69-70)
-            const float pt[3] = {in_o[tl][0] + in_d[tl][0] * in_z[p], in_o[tl][1] + in_d[tl][1] * in_z[p], in_o[tl][2] + in_d[tl][2] * in_z[p]};
+            const float pt[3] = {(t1 ? in_o[1][0] : in_o[0][0]) + (t1 ? in_d[1][0] : in_d[0][0]) * in_z,
+                                 (t1 ? in_o[1][1] : in_o[0][1]) + (t1 ? in_d[1][1] : in_d[0][1]) * in_z,
+                                 (t1 ? in_o[1][2] : in_o[0][2]) + (t1 ? in_d[1][2] : in_d[0][2]) * in_z};
             float sn[LX][3], cs[LX][3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -571,24 +576,24 @@ void mlp_bf16_kernel(const MlpArgsB a) {
                 const int k = (u - 3) / 6, r = (u - 3) % 6;
                 return r < 3 ? sn[k][r] : cs[k][r - 3];
             };
-            auto sel4 = [&](float c0, float c1, float c2, float c3) __attribute__((always_inline)) -> float {      // by lane quarter
-                const float lo = (q4 & 1) ? c1 : c0, hi = (q4 & 1) ? c3 : c2;
-                return (q4 & 2) ? hi : lo;
-            };
+            // fragment (point tile q4, k-step ks): lane quarter qq reads channels 32 ks + 8 qq + j of point `col` at
+            // [fragment][(qq * 16 + col) * 16 bytes]: this lane writes those 16 bytes for every qq
+            char* wr = pe_wave + (q4 * KPE) * QUAD_BYTES + col * 16;
 #pragma unroll
-            for (int ks = 0; ks < KPE; ++ks) {
-                u32x4b v;
+            for (int ks = 0; ks < KPE; ++ks)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int u = KF * ks + 2 * i;                      // element 2i of lane quarter 0; quarter q: + 8q
-                    const float lo = sel4(chan(u), chan(u + 8), chan(u + 16), chan(u + 24));
-                    const float hi = sel4(chan(u + 1), chan(u + 9), chan(u + 17), chan(u + 25));
-                    v[i] = pack2(lo, hi);
+                for (int qq = 0; qq < 4; ++qq) {
+                    u32x4b v;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = pack2(chan(KF * ks + 8 * qq + 2 * i), chan(KF * ks + 8 * qq + 2 * i + 1));
+                    *(u32x4b*)(wr + ks * QUAD_BYTES + qq * 256) = v;
                 }
-                peb[p][ks] = v;
-                *(u32x4b*)(pe_lds + (p * KPE + ks) * QUAD_BYTES) = v;
-            }
         }
+        // LDS operations of one wave execute in order: the fragments written above are complete when these reads return
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+            for (int ks = 0; ks < KPE; ++ks) peb[p][ks] = *(const u32x4b*)(pe_lds + (p * KPE + ks) * QUAD_BYTES);
         // hoisted view-direction term of linear_d (fp32), per 32-sample tile: scratch[tl][n] = b_d[n] + sum_f Wd[n][W+f] * gamma(d/|d|)[f]
 #pragma unroll
         for (int tl = 0; tl < 2; ++tl) {

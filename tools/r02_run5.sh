@@ -4,7 +4,7 @@ set -o pipefail
 export TMPDIR=/tmp
 O=gpurun_out/r2p
 mkdir -p $O
-B="python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --frames 0 --train-steps 0 --no-small-batch"
+B="python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --frames 0 --train-steps 0 --no-small-batch --no-bf16-leg"
 # the rocpd databases are ~7 MB each and only 64 MiB travel back: summarise on the box, keep the JSON
 run() { tag=$1; shift; timeout -k 10 240 rocprofv3 "$@" > $O/$tag.log 2>&1; echo "$tag rc=$?"; python3 tools/rocpd_summary.py $O/$tag/r_results.db --last 3 > $O/$tag.json 2>>$O/$tag.log; rm -rf $O/$tag; tail -c 2000 $O/$tag.log > $O/$tag.log.tail; rm -f $O/$tag.log; }
 run fp32_stats --kernel-trace --stats -d $O/fp32_stats -o r -- $B
