@@ -18,6 +18,7 @@
 //   * pack_apply_kernel    device-side re-pack of the weight blobs after optimizer.step().
 // Nothing is differentiated w.r.t. the sample positions or view directions: the reference's only trainable
 // tensors are the MLP parameters (train.py:149-152).
+#include <type_traits>
 #include <vector>
 #include "mlp_core.h"
 
@@ -208,18 +209,37 @@ __device__ __attribute__((aligned(16))) float g_zero16[4];      // read through 
 // Operand fetch: ONE 16-byte load per lane per point pair and operand: lane i takes columns 4i..4i+3, i.e. MFMA tile
 // t of this wave covers columns {4i + t}.  Any bijection lane <-> column works as long as the store uses the same one.
 // Requires M, N, ldd, ldx multiples of 4 and 16-byte aligned operands (true for every W-wide layer).
+//
+// What a non-MFMA instruction costs here (tools/mfma_probe5.hip, cycles from a PMC pass): v_mfma_f32_32x32x2_f32 runs on the
+// SIMD's fp32 lanes, so VALU work does NOT hide behind it -- every VALU instruction takes its 4 issue cycles out of the matrix
+// rate plus ~8 cycles for each MFMA gap that holds any (14 v_add_f32 per 16 MFMAs: 66 -> 73-76 cycles per MFMA; in one gap: 70);
+// SALU instructions and s_nop are free.  The first version of this loop spent ~25 VALU per k-step on addresses (64-bit row *
+// pitch, the row < P and column < M selects) and the bias sums: 84 % of the MFMA rate in cycles.  Now the loop has NO vector
+// address arithmetic: rows come through buffer loads whose descriptor (base = first row of the 12-row group, num_records = the
+// bytes of that group that exist) is rebuilt per group on the SALU, the per-lane offsets of the six k-steps are loop constants,
+// and the hardware's range check returns zeros for rows at or past P and for lanes whose columns do not exist (offset 2^31).
+// The bias sums (4 v_add per k-step) are split between the two waves that hold the same delta columns (even / odd k-steps).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wg_rsrc(const float* base, long long row0, long long ld, long long P, int rows) {
+    long long left = P - row0;                                   // rows of this group that exist (wave-uniform: SALU)
+    left = left < 0 ? 0 : (left > rows ? rows : left);
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(base + row0 * ld), 0, (int)(left * ld * 4), 0x00020000);
+}
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void wgrad_big_kernel(const WgradArgs a) {
     constexpr int U = 6;                  // k-steps (2 points each) per software-pipeline stage
+    __shared__ f32x4 bshare[2][64];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 31, kh = lane >> 5;
     const int b = blockIdx.y;                                    // product of the batch
-    const int m0 = (wave >> 1) * 128, n0 = (wave & 1) * 128;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = wm * 128, n0 = wn * 128;
     const bool aok = m0 + 4 * i < a.M[b], bok = n0 + 4 * i < a.N[b];
-    const float* abase = a.dlt[b] + m0 + 4 * i;
-    const float* bbase = a.x[b] + n0 + 4 * i;
+    const float* abase = a.dlt[b];
+    const float* bbase = a.x[b];
     const long long ldd = a.ldd[b], ldx = a.ldx[b];
+    const bool want_bias = a.want_bias[b] != 0;
 
     f32x16 acc[4][4];
 #pragma unroll
@@ -233,48 +253,64 @@ void wgrad_big_kernel(const WgradArgs a) {
     // The points are dealt to the workgroups in GROUPS of 2U rows, round robin: group g of workgroup s is rows
     // [(g * slices + s) * 2U, ... + 2U).  At any moment the whole chip streams one window of slices x 2U consecutive rows per
     // operand (3 MB) instead of 256 separate regions hundreds of MB apart -- contiguous per-workgroup slices lose 10-25 % to
-    // the memory system as P grows (tools/wgrad_probe.py).  Rows at or past P are never fetched: the address is switched to
-    // a zero buffer (a value select after the load would wrap every load in an exec-masked block with its own s_waitcnt).
+    // the memory system as P grows (tools/wgrad_probe.py).  Rows at or past P are never fetched (range check, above).
     // Three register sets rotated by NAME (loop unrolled by 3; a copy of a just-requested set forces s_waitcnt vmcnt(0)),
     // and the two loads of a k-step are issued right behind the 16 MFMAs of the same k-step of the current set.
     const long long slices = gridDim.x;
-    const long long gstride = slices * (2 * U);              // rows between consecutive groups of one workgroup
-    long long req_row = (long long)blockIdx.x * (2 * U) + kh;     // next row this lane half requests
-    int req_u = 0;
+    unsigned voa[U], vob[U];                                      // byte offsets inside a group: row 2u + kh, columns m0 + 4i..
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        voa[u] = aok ? (unsigned)(((2 * u + kh) * ldd + m0 + 4 * i) * 4) : 0x80000000u;
+        vob[u] = bok ? (unsigned)(((2 * u + kh) * ldx + n0 + 4 * i) * 4) : 0x80000000u;
+    }
+    long long req_group = blockIdx.x;                             // global index of the next group this workgroup requests
     f32x4 ca[U], cb[U], na[U], nb[U], fa[U], fb[U];
-    auto request = [&](f32x4& A, f32x4& B) __attribute__((always_inline)) {
-        const bool in = req_row < a.P;
-        const f32x4* qa = (in && aok) ? (const f32x4*)(abase + req_row * ldd) : (const f32x4*)g_zero16;
-        const f32x4* qb = (in && bok) ? (const f32x4*)(bbase + req_row * ldx) : (const f32x4*)g_zero16;
-        A = *qa;
-        B = *qb;
-        req_row += 2;
-        if (++req_u == U) { req_u = 0; req_row += gstride - 2 * U; }
+    __amdgpu_buffer_rsrc_t ra, rb;
+    auto open_group = [&]() __attribute__((always_inline)) {
+        const long long row0 = req_group * (2 * U);
+        ra = wg_rsrc(abase, row0, ldd, a.P, 2 * U);
+        rb = wg_rsrc(bbase, row0, ldx, a.P, 2 * U);
+        req_group += slices;
     };
+    auto request = [&](int u, f32x4& A, f32x4& B) __attribute__((always_inline)) {
+        A = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, voa[u], 0, 0));
+        B = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, vob[u], 0, 0));
+    };
+    open_group();
 #pragma unroll
-    for (int u = 0; u < U; ++u) request(ca[u], cb[u]);
+    for (int u = 0; u < U; ++u) request(u, ca[u], cb[u]);
+    open_group();
 #pragma unroll
-    for (int u = 0; u < U; ++u) request(na[u], nb[u]);
-    auto step = [&](f32x4 (&A)[U], f32x4 (&B)[U], f32x4 (&FA)[U], f32x4 (&FB)[U]) __attribute__((always_inline)) {
+    for (int u = 0; u < U; ++u) request(u, na[u], nb[u]);
+    // PAR: which k-steps of a group this wave adds to the bias sums (0 even, 1 odd, -1 none).  A compile-time property of
+    // the loop: as a run-time condition hipcc turns it into add + select on every k-step.
+    auto step = [&](auto PAR, f32x4 (&A)[U], f32x4 (&B)[U], f32x4 (&FA)[U], f32x4 (&FB)[U]) __attribute__((always_inline)) {
+        constexpr int par = decltype(PAR)::value;
+        open_group();
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            bsum += A[u];
 #pragma unroll
             for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
                 for (int tn = 0; tn < 4; ++tn)
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[u][tm], B[u][tn], acc[tm][tn], 0, 0, 0);
-            request(FA[u], FB[u]);
+            if ((u & 1) == par) bsum += A[u];
+            request(u, FA[u], FB[u]);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
     const long long all_groups = (a.P + 2 * U - 1) / (2 * U);
     const long long n_groups = (all_groups + slices - 1) / slices;       // per workgroup; surplus groups multiply zeros
-    for (long long g = 0; g < n_groups; g += 3) {
-        step(ca, cb, fa, fb);
-        step(na, nb, ca, cb);
-        step(fa, fb, na, nb);
-    }
+    auto loop = [&](auto PAR) __attribute__((always_inline)) {
+        for (long long g = 0; g < n_groups; g += 3) {
+            step(PAR, ca, cb, fa, fb);
+            step(PAR, na, nb, ca, cb);
+            step(PAR, fa, fb, na, nb);
+        }
+    };
+    if (!want_bias) loop(std::integral_constant<int, -1>{});
+    else if (wn == 0) loop(std::integral_constant<int, 0>{});
+    else loop(std::integral_constant<int, 1>{});
     // D[i'][j]: i' = (r&3) + 8*(r>>2) + 4*kh is the A-side lane index, j = lane & 31 the B-side one
     float* out = a.partial + ((size_t)b * a.slices + blockIdx.x) * (256 * 256);
 #pragma unroll
@@ -285,11 +321,16 @@ void wgrad_big_kernel(const WgradArgs a) {
             f32x4 v; v[0] = acc[tm][0][r]; v[1] = acc[tm][1][r]; v[2] = acc[tm][2][r]; v[3] = acc[tm][3][r];
             *(f32x4*)(out + (size_t)m * 256 + n0 + 4 * i) = v;
         }
-    if (a.want_bias[b] && (wave & 1) == 0) {
-        f32x4 sv;
+    if (want_bias) {                                             // uniform over the workgroup
+        if (wn == 1) bshare[wm][lane] = bsum;                    // odd k-steps of the same columns
+        __syncthreads();
+        if (wn == 0) {
+            bsum += bshare[wm][lane];
+            f32x4 sv;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) sv[e] = bsum[e] + __shfl_xor(bsum[e], 32, 64);      // even + odd points of every k-step
-        if (kh == 0) *(f32x4*)(a.bpartial + ((size_t)b * a.slices + blockIdx.x) * 256 + m0 + 4 * i) = sv;
+            for (int e = 0; e < 4; ++e) sv[e] = bsum[e] + __shfl_xor(bsum[e], 32, 64);      // even + odd points of every k-step
+            if (kh == 0) *(f32x4*)(a.bpartial + ((size_t)b * a.slices + blockIdx.x) * 256 + m0 + 4 * i) = sv;
+        }
     }
 }
 
