@@ -420,14 +420,14 @@ __global__ __launch_bounds__(256) void sample_pdf_kernel(const float* __restrict
 
 // fine branch: bins = mid(z_c), weights = weights_c[1:-1], then sort(cat(z_c, samples))   (:63-67)
 __global__ __launch_bounds__(256) void fine_z_kernel(const float* __restrict__ z_c, const float* __restrict__ w_c, long long n,
-                                                      int Sc, int Nf, int det, const float* __restrict__ u,
+                                                      int Sc, int Nf, int n2, int det, const float* __restrict__ u,
                                                       float* __restrict__ z_f, float* __restrict__ z_samp) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const long long ray = (long long)blockIdx.x * 4 + wv;
     if (ray >= n) return;
     const int B = Sc - 1, St = Sc + Nf;
-    float* cdf = lds + wv * (2 * B + St);
+    float* cdf = lds + wv * (2 * B + n2);                   // n2: Sc + Nf rounded up to a power of two (the sort network)
     float* bn = cdf + B;
     float* all = bn + B;
     const float* zr = z_c + ray * Sc;
@@ -444,21 +444,40 @@ __global__ __launch_bounds__(256) void fine_z_kernel(const float* __restrict__ z
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    // rank sort (values only matter, ties broken by position): rank = #smaller + #equal-before.  NaN depths (a diverged
-    // network: NaN weights -> NaN samples) compare as +inf, so they rank LAST in position order like torch.sort places them
-    // (nerf_process.py:67) and every output slot is written exactly once -- with plain float compares several NaNs would share
-    // a rank and leave slots of z_f (torch.empty) uninitialised.
-    for (int e = lane; e < St; e += 64) {
-        const float v = all[e];
-        const float vk = (v != v) ? __builtin_inff() : v;
-        int rank = 0;
-        for (int k = 0; k < St; ++k) {
-            const float o = all[k];
-            const float ok = (o != o) ? __builtin_inff() : o;
-            rank += (ok < vk || (ok == vk && k < e)) ? 1 : 0;
-        }
-        z_f[ray * St + rank] = v;
+    // sort(cat(z_c, samples)) (nerf_process.py:67): only the sorted VALUES are returned, so any correct sort gives the reference's
+    // tensor.  Bitonic network over the wave's LDS slice, padded to a power of two with +inf: log2(n2)(log2(n2)+1)/2 stages of
+    // n2/2 compare-exchanges (36 stages of 2 per lane for 64 + 128 samples; the rank sort this replaces did St compares for each
+    // of St/64 elements per lane -- 48 k cycles per ray, 23 us per launch however few the rays).  NaN depths (a diverged
+    // network: NaN weights -> NaN samples) are sorted as +inf and written back as NaN in the last slots, where torch.sort
+    // places them; every slot of z_f (torch.empty) is written.
+    int nan_here = 0;
+    for (int e = lane; e < n2; e += 64) {
+        const float v = e < St ? all[e] : __builtin_inff();
+        const bool isn = v != v;
+        nan_here += isn ? 1 : 0;
+        if (isn || e >= St) all[e] = __builtin_inff();
     }
+    int n_nan = nan_here;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n_nan += __shfl_xor(n_nan, o, 64);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    for (int k = 2; k <= n2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = lane; t < (n2 >> 1); t += 64) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));       // t with a 0 inserted at bit log2(j)
+                const int l = i | j;
+                const float x = all[i], y = all[l];
+                const bool lt = x < y;
+                const float lo = lt ? x : y, hi = lt ? y : x;
+                const bool up = (i & k) == 0;
+                all[i] = up ? lo : hi;
+                all[l] = up ? hi : lo;
+            }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+    for (int e = lane; e < St; e += 64) z_f[ray * St + e] = e < St - n_nan ? all[e] : __builtin_nanf("");
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -590,13 +609,16 @@ int stage_sample_pdf(const float* bins, const float* weights, int64_t n, int B, 
 
 int stage_fine_z(const float* z_c, const float* w_c, int64_t n, int Sc, int Nf, int det, const float* u, float* z_f, float* z_samp,
                  hipStream_t st) {
-    // 4 rays per block, 2(Sc-1) + Sc + Nf floats each, within the 64 KB of dynamic LDS a launch gets without opting in
-    MN_CHECK_ARG(n >= 0 && Sc >= 3 && Nf >= 1 && 2 * (Sc - 1) + Sc + Nf <= MAX_LDS_FLOATS_PER_RAY, "bad sizes (Sc=%d Nf=%d: 3*Sc + Nf - 2 must not exceed %d)",
-                 Sc, Nf, MAX_LDS_FLOATS_PER_RAY);
+    // 4 rays per block, 2(Sc-1) + pow2(Sc + Nf) floats each, within the 64 KB of dynamic LDS a launch gets without opting in
+    MN_CHECK_ARG(n >= 0 && Sc >= 3 && Nf >= 1 && Sc + Nf <= MAX_LDS_FLOATS_PER_RAY, "bad sizes (Sc=%d Nf=%d)", Sc, Nf);
+    int n2 = 2;
+    while (n2 < Sc + Nf) n2 <<= 1;
+    MN_CHECK_ARG(2 * (Sc - 1) + n2 <= MAX_LDS_FLOATS_PER_RAY, "bad sizes (Sc=%d Nf=%d: 2*(Sc-1) + %d (Sc+Nf rounded up to a power of two) must not exceed %d)",
+                 Sc, Nf, n2, MAX_LDS_FLOATS_PER_RAY);
     if (n == 0) return MI_NERF_OK;
     MN_CHECK_ARG(z_c && w_c && z_f && (det || u), "NULL pointer");
-    const size_t lds = (size_t)4 * (2 * (Sc - 1) + Sc + Nf) * sizeof(float);
-    hipLaunchKernelGGL(fine_z_kernel, dim3(blocks_for(n, 4)), dim3(256), lds, st, z_c, w_c, (long long)n, Sc, Nf, det, u, z_f, z_samp);
+    const size_t lds = (size_t)4 * (2 * (Sc - 1) + n2) * sizeof(float);
+    hipLaunchKernelGGL(fine_z_kernel, dim3(blocks_for(n, 4)), dim3(256), lds, st, z_c, w_c, (long long)n, Sc, Nf, n2, det, u, z_f, z_samp);
     MN_LAUNCH_CHECK("fine_z_kernel");
     return MI_NERF_OK;
 }

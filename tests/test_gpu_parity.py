@@ -147,6 +147,27 @@ def test_sample_pdf_F4(golden):
     assert ff <= 5e-3, ff                                # observed 2.7e-3
 
 
+@pytest.mark.parametrize("n,Sc,Nf", [(37, 64, 128), (5, 3, 1), (9, 17, 40), (4, 64, 192), (3, 200, 821), (2, 1024, 1024)])
+def test_fine_z_sort_is_torch_sort(n, Sc, Nf):
+    """sort(cat(z_c, samples)) (nerf_process.py:67) for sample counts that are not powers of two (the sort network pads), with
+    repeated depths, and with NaN weights (a diverged network): NaNs last like torch.sort, every slot written."""
+    g = torch.Generator().manual_seed(n * Sc + Nf)
+    z_c = torch.sort(2.0 + 4.0 * torch.rand(n, Sc, generator=g), -1)[0]
+    z_c[:, Sc // 2] = z_c[:, Sc // 2 - 1]                                  # a tie
+    w = torch.rand(n, Sc, generator=g)
+    u = torch.rand(n, Nf, generator=g)
+    zf, zs = ops.fine_z(z_c.to(DEV), w.to(DEV), Nf, False, u.to(DEV), want_samples=True)
+    assert torch.equal(torch.sort(torch.cat([z_c.to(DEV), zs], -1), -1)[0], zf)
+    want_s, _ = R.fine_z(z_c, w, Nf, False, u)
+    if zf.numel() >= 1000:
+        assert _flip_fraction(zf, want_s, 5e-6) <= 2e-2
+    if n > 1:
+        w[0, 1] = float("nan")                                              # ray 0: every sample NaN, the coarse depths are not
+        zf = ops.fine_z(z_c.to(DEV), w.to(DEV), Nf, False, u.to(DEV))
+        assert torch.equal(zf[0, :Sc], z_c[0].to(DEV)) and bool(torch.isnan(zf[0, Sc:]).all())
+        assert not bool(torch.isnan(zf[1:]).any())
+
+
 def test_posenc_embed_F5(golden):
     g = golden("F5_posenc")
     f10, d10 = get_positional_encoder(10)

@@ -27,6 +27,15 @@ def main():
         out["kernels"].append({"name": name[:120], "launches": len(rs), "total_ms": round(sum(d) / 1e6, 4), "avg_us": round(sum(d) / len(d) / 1e3, 2),
                                "median_us": round(d[len(d) // 2] / 1e3, 2), "min_us": round(d[0] / 1e3, 2), "max_us": round(d[-1] / 1e3, 2),
                                **{k: rs[-1][ix[k]] for k in ("grid_size_x", "workgroup_size_x", "lds_size", "scratch_size", "vgpr_count", "accum_vgpr_count", "sgpr_count") if k in ix}})
+    if "--timeline" in sys.argv:                  # the last N dispatches in time order: start relative to the first of them, duration, gap to the previous end
+        n = int(sys.argv[sys.argv.index("--timeline") + 1])
+        tl = sorted(rows, key=lambda r: r[ix["start"]])[-n:]
+        t0, prev = tl[0][ix["start"]], None
+        out["timeline"] = []
+        for r in tl:
+            out["timeline"].append({"name": r[ix["name"]][:60], "start_us": round((r[ix["start"]] - t0) / 1e3, 2), "dur_us": round(r[ix["duration"]] / 1e3, 2),
+                                    "gap_us": None if prev is None else round((r[ix["start"]] - prev) / 1e3, 2)})
+            prev = r[ix["end"]]
     try:
         ccols = [r[1] for r in c.execute("pragma table_info(counters_collection)")]
         cix = {n: i for i, n in enumerate(ccols)}
