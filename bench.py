@@ -137,8 +137,10 @@ def worker(args) -> None:
         raise SystemExit(f"{world} ranks but {ndev} GPU(s): RCCL needs one GPU per rank (BENCH_BACKEND=gloo rehearses the plumbing)")
     dev = torch.device("cuda", local_rank % ndev)
     torch.cuda.set_device(dev)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"      # BENCH_FORCE_DIST: a 1-rank RCCL group on a one-GPU box
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -150,11 +152,11 @@ def worker(args) -> None:
     from nerf_pytorch_paeng_amd import ops, synthetic, weights
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     def max_over_ranks(t: float) -> float:
-        if world == 1:
+        if not use_dist:
             return t
         tm = torch.tensor([t], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
@@ -469,7 +471,7 @@ def worker(args) -> None:
         if cpu is not None:
             line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         barrier()                      # rank 0 may still be printing / staging: tear the group down together
         dist.destroy_process_group()
 

@@ -29,9 +29,11 @@ def shard_range(n: int, world: int, rank: int) -> Tuple[int, int]:
     return shard_rows(n, world, rank)
 
 
-def gather_tiles(local: torch.Tensor, H: int, W: int, group=None) -> torch.Tensor:
-    """All-gather per-rank ``[rows_local * W, C]`` tiles into the full ``[H * W, C]`` frame on every rank."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+def gather_tiles(local: torch.Tensor, H: int, W: int, group=None, force_collective: bool = False) -> torch.Tensor:
+    """All-gather per-rank ``[rows_local * W, C]`` tiles into the full ``[H * W, C]`` frame on every rank.
+    A group of one rank returns its tile as is; ``force_collective`` sends it through the collective anyway (a one-GPU box can
+    then exercise the RCCL call path itself)."""
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force_collective):
         return local
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     C = local.shape[1]

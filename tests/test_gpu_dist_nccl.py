@@ -77,6 +77,52 @@ def test_nccl_two_rank_frame_is_bit_identical_to_one_rank(tmp_path, H, W):
         np.testing.assert_array_equal(np.load(tmp_path / f"disp_{r}.npy"), disp.cpu().numpy())
 
 
+def _nccl_one_rank_worker(_index, port, H, W, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        from nerf_pytorch_paeng_amd import dist as mdist
+        packed, K, pose, opts = _scene(dev, H, W)
+        rgb, disp = mdist.render_frame(H, W, K, pose, packed, opts, seed=3)
+        tile = torch.cat([rgb.reshape(-1, 3), disp.reshape(-1, 1)], -1).contiguous()
+        full = mdist.gather_tiles(tile, H, W, force_collective=True)             # all_gather_into_tensor on RCCL itself
+        t = torch.tensor([1.5], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+        np.save(os.path.join(out_dir, "tile.npy"), tile.cpu().numpy())
+        np.save(os.path.join(out_dir, "full.npy"), full.cpu().numpy())
+        assert float(t.item()) == 1.5
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_rccl_call_path_with_one_rank(tmp_path):
+    """What a one-GPU box can exercise of the RCCL leg: init_process_group("nccl", device_id=...), the tile all-gather, the timing
+    all-reduce and the barrier run against RCCL in a group of one rank (own process: the group must not leak into other tests)."""
+    H, W = 24, 20
+    mp.spawn(_nccl_one_rank_worker, args=(_free_port(), H, W, str(tmp_path)), nprocs=1, join=True)
+    np.testing.assert_array_equal(np.load(tmp_path / "tile.npy"), np.load(tmp_path / "full.npy"))
+
+
+@pytest.mark.timeout(900)
+def test_bench_one_rank_through_rccl():
+    """`python bench.py` with BENCH_FORCE_DIST=1: the worker's RCCL set-up, barriers and max-over-ranks all-reduce at world size 1."""
+    env = dict(os.environ, BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--frames", "0", "--train-steps", "0",
+                        "--no-cpu-baseline", "--no-small-batch", "--no-bf16-leg"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["value"] > 1e5
+
+
 @pytest.mark.timeout(900)
 def test_bench_launches_its_own_workers():
     env = dict(os.environ)
