@@ -201,10 +201,6 @@ struct ReduceBatch {                      // where each product of a batch goes 
     int ldo[WG_MAXB], M[WG_MAXB], N[WG_MAXB];
 };
 
-// masked lanes / rows past the slice end load zeros from here WITHOUT a branch (a value select after the load makes
-// hipcc wrap every load in its own exec-masked block with an immediate s_waitcnt: 6x slower).  Never written.
-__device__ __attribute__((aligned(16))) float g_zero16[4];      // read through f32x4*: 16-byte aligned
-
 // 256 x 256 block of dW per workgroup: 2x2 waves, each 4x4 MFMA tiles (all 256 accumulator registers).
 // Operand fetch: ONE 16-byte load per lane per point pair and operand: lane i takes columns 4i..4i+3, i.e. MFMA tile
 // t of this wave covers columns {4i + t}.  Any bijection lane <-> column works as long as the store uses the same one.
@@ -302,11 +298,13 @@ void wgrad_big_kernel(const WgradArgs a) {
     const long long all_groups = (a.P + 2 * U - 1) / (2 * U);
     const long long n_groups = (all_groups + slices - 1) / slices;       // per workgroup; surplus groups multiply zeros
     auto loop = [&](auto PAR) __attribute__((always_inline)) {
-        for (long long g = 0; g < n_groups; g += 3) {
+        long long g = 0;
+        do {
             step(PAR, ca, cb, fa, fb);
             step(PAR, na, nb, ca, cb);
             step(PAR, fa, fb, na, nb);
-        }
+            g += 3;
+        } while (g < n_groups);
     };
     if (!want_bias) loop(std::integral_constant<int, -1>{});
     else if (wn == 0) loop(std::integral_constant<int, 0>{});
@@ -350,10 +348,12 @@ struct NarrowArgs {
     float* nsum;                             // [slices][32 NN]   column sums of the narrow operand, or NULL
 };
 
-template <int WQ, int NN>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
+// BW / BN: column sums of the wide / narrow operand wanted (the bias gradient of the layer).  Compile-time: VALU work beside
+// fp32 MFMAs is never free (see wgrad_big_kernel), so the sums exist only in the instantiations that return them.
+template <int WQ, int NN, bool BW, bool BN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, (WQ * NN == 4) ? 1 : 2)))
 void wgrad_narrow_kernel(const NarrowArgs a) {
-    constexpr int U = (WQ == 2) ? 4 : 6;      // k-steps per pipeline stage: 3 register sets next to 64 WQ NN accumulators, no scratch
+    constexpr int U = (WQ == 2) ? 4 : 6;      // k-steps per pipeline stage: 3 register sets next to 64 WQ NN accumulators
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 31, kh = lane >> 5;
@@ -361,21 +361,21 @@ void wgrad_narrow_kernel(const NarrowArgs a) {
     // workgroup writes ONE partial, so the reduction kernel sees a quarter of the slices
     const long long slice = (long long)blockIdx.x * 4 + wave;
     const long long pb = slice * a.pps;
-    const bool active = pb < a.P;            // tail waves past the last slice multiply zeros and still join the barriers
-    const long long pe = !active ? pb : ((pb + a.pps < a.P) ? pb + a.pps : a.P);
+    const long long pe = pb >= a.P ? pb : ((pb + a.pps < a.P) ? pb + a.pps : a.P);   // tail waves: empty slice, still join the barriers
+    const long long ldw = a.ldw, ldn = a.ldn;
 
-    bool wok[WQ], nok[NN];
-    const float* pw[WQ];
-    long long sw[WQ];
+    // Operands through buffer loads, as in wgrad_big_kernel: the descriptor of a group of 2U rows is rebuilt on the SALU (base = the
+    // group's first row, num_records = the bytes of it inside [pb, pe)), the per-lane offsets of the U k-steps are loop constants,
+    // and the range check zeroes rows past the slice end and lanes whose column does not exist: no address arithmetic, no
+    // row < P selects and no zeroing of over-fetched values on the VALU, and nothing is read outside the operands' P rows.
+    unsigned vow[U][WQ], von[U][NN];
 #pragma unroll
-    for (int q = 0; q < WQ; ++q) {
-        wok[q] = active && pb + kh < a.P && 128 * q + 4 * i < a.Mw;
-        pw[q] = wok[q] ? a.wide + (pb + kh) * a.ldw + 128 * q + 4 * i : g_zero16;
-        sw[q] = wok[q] ? (long long)a.ldw * 2 : 0;
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int q = 0; q < WQ; ++q) vow[u][q] = (128 * q + 4 * i < a.Mw) ? (unsigned)(((2 * u + kh) * ldw + 128 * q + 4 * i) * 4) : 0x80000000u;
+#pragma unroll
+        for (int q = 0; q < NN; ++q) von[u][q] = (32 * q + i < a.Nn) ? (unsigned)(((2 * u + kh) * ldn + 32 * q + i) * 4) : 0x80000000u;
     }
-    const float* pn[NN];
-#pragma unroll
-    for (int q = 0; q < NN; ++q) { nok[q] = active && 32 * q + i < a.Nn; pn[q] = a.nar + 32 * q + i; }
 
     f32x16 acc[4 * WQ][NN];
 #pragma unroll
@@ -391,52 +391,47 @@ void wgrad_narrow_kernel(const NarrowArgs a) {
 #pragma unroll
     for (int q = 0; q < NN; ++q) nsum[q] = 0.0f;
 
-    // three register sets rotated by name, loads behind each k-step's MFMAs, rows past the slice end zeroed in both
-    // operands: see wgrad_big_kernel.  The load pipeline runs up to five groups ahead of the slice end; neither operand is ever
-    // read outside its P rows (narrow: requests for rows >= P are switched to the zero buffer by ADDRESS; wide: the pointer stops).
     struct Set { f32x4 w[U][WQ]; float n[U][NN]; };
     Set c, nx, f;
-    long long row = pb + kh;                 // next row to request for this lane half
-    auto request = [&](Set& S, int u) __attribute__((always_inline)) {
-        // the wide pointer stops advancing at this lane half's last row (the re-read values are zeroed below like every row past
-        // the slice end): the pipeline runs up to five groups ahead of the data but never reads past row P - 1
-        const long long keep = (row + 2 < a.P) ? -1LL : 0LL;
-#pragma unroll
-        for (int q = 0; q < WQ; ++q) { S.w[u][q] = *(const f32x4*)pw[q]; pw[q] += sw[q] & keep; }
-        const bool in = row < a.P;
-#pragma unroll
-        for (int q = 0; q < NN; ++q) {
-            const float* p = (in && nok[q]) ? pn[q] + row * a.ldn : g_zero16;
-            S.n[u][q] = *p;
-        }
-        row += 2;
+    long long req_row = pb;                  // first row of the next group to request (wave-uniform)
+    __amdgpu_buffer_rsrc_t rw, rn;
+    auto open_group = [&]() __attribute__((always_inline)) {
+        rw = wg_rsrc(a.wide, req_row, ldw, pe, 2 * U);
+        rn = wg_rsrc(a.nar, req_row, ldn, pe, 2 * U);
+        req_row += 2 * U;
     };
+    auto request = [&](Set& S, int u) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < WQ; ++q) S.w[u][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, vow[u][q], 0, 0));
+#pragma unroll
+        for (int q = 0; q < NN; ++q) S.n[u][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rn, von[u][q], 0, 0));
+    };
+    open_group();
 #pragma unroll
     for (int u = 0; u < U; ++u) request(c, u);
+    open_group();
 #pragma unroll
     for (int u = 0; u < U; ++u) request(nx, u);
-    int rows_left = (int)(pe - pb) - kh;
     auto step = [&](Set& A, Set& F) __attribute__((always_inline)) {
+        open_group();
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const bool ok = 2 * u < rows_left;
-#pragma unroll
-            for (int q = 0; q < WQ; ++q) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) A.w[u][q][e] = ok ? A.w[u][q][e] : 0.0f;
-                wsum[q] += A.w[u][q];
-            }
-#pragma unroll
-            for (int q = 0; q < NN; ++q) { A.n[u][q] = ok ? A.n[u][q] : 0.0f; nsum[q] += A.n[u][q]; }
 #pragma unroll
             for (int tm = 0; tm < 4 * WQ; ++tm)
 #pragma unroll
                 for (int tn = 0; tn < NN; ++tn)
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(A.w[u][tm >> 2][tm & 3], A.n[u][tn], acc[tm][tn], 0, 0, 0);
+            if (BW) {
+#pragma unroll
+                for (int q = 0; q < WQ; ++q) wsum[q] += A.w[u][q];
+            }
+            if (BN) {
+#pragma unroll
+                for (int q = 0; q < NN; ++q) nsum[q] += A.n[u][q];
+            }
             request(F, u);
             __builtin_amdgcn_sched_barrier(0);
         }
-        rows_left -= 2 * U;
     };
     const long long n_groups = (pe - pb + 2 * U - 1) / (2 * U);
     for (long long g = 0; g < n_groups; g += 3) {
@@ -576,7 +571,9 @@ __global__ __launch_bounds__(256) void pack_apply_kernel(const int32_t* __restri
 static int num_cus_t() { return device_cus(); }
 
 static inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
-// wgrad_narrow_kernel's load pipeline runs up to 5 groups x 12 rows x 1 KiB past the end of its wide operand
+// Slack behind the operands whose rows are narrower than 1 KB.  The first weight-gradient kernels ran their load pipelines past the
+// end of a point slice and needed it; the current ones fetch through range-checked buffer loads and read nothing outside rows
+// [0, P).  Kept: it costs 256 KB and leaves the layout (mi_nerf_train_layout_query) unchanged.
 constexpr size_t WGRAD_OVERRUN_PAD = 128 * 1024;
 
 constexpr size_t WGRAD_PARTIAL_FLOATS = (size_t)256 * 256 * 256 + (size_t)256 * 256;   // 256 slices of a 256x256 block + bias rows
@@ -673,10 +670,18 @@ static int run_wgrad(const float* dlt, int ldd, int M, const float* x, int ldx, 
     a.wsum = (bias && delta_is_wide) ? wsum : nullptr;
     a.nsum = (bias && !delta_is_wide) ? nsum : nullptr;
     const dim3 grid((unsigned)slices);
-    if (WQ == 2 && NN == 2) hipLaunchKernelGGL((wgrad_narrow_kernel<2, 2>), grid, dim3(256), 0, st, a);
-    else if (WQ == 2) hipLaunchKernelGGL((wgrad_narrow_kernel<2, 1>), grid, dim3(256), 0, st, a);
-    else if (NN == 2) hipLaunchKernelGGL((wgrad_narrow_kernel<1, 2>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((wgrad_narrow_kernel<1, 1>), grid, dim3(256), 0, st, a);
+    const bool bw = a.wsum != nullptr, bn = a.nsum != nullptr;
+#define MN_NARROW(WQ_, NN_)                                                                                                   \
+    do {                                                                                                                      \
+        if (bw) hipLaunchKernelGGL((wgrad_narrow_kernel<WQ_, NN_, true, false>), grid, dim3(256), 0, st, a);                  \
+        else if (bn) hipLaunchKernelGGL((wgrad_narrow_kernel<WQ_, NN_, false, true>), grid, dim3(256), 0, st, a);             \
+        else hipLaunchKernelGGL((wgrad_narrow_kernel<WQ_, NN_, false, false>), grid, dim3(256), 0, st, a);                    \
+    } while (0)
+    if (WQ == 2 && NN == 2) MN_NARROW(2, 2);
+    else if (WQ == 2) MN_NARROW(2, 1);
+    else if (NN == 2) MN_NARROW(1, 2);
+    else MN_NARROW(1, 1);
+#undef MN_NARROW
     MN_LAUNCH_CHECK("wgrad_narrow_kernel");
     const int total = M * N + (bias ? M : 0);
     // reduce: rows of the partial are the wide index.  delta wide: out[m][n] = partial[m][n];  delta narrow: out[m][n] = partial[n][m]
