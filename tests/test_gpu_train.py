@@ -274,7 +274,7 @@ def test_fine_loss_does_not_reach_coarse_network():
         assert (p.grad is None) == k.startswith("model_coarse."), k
 
 
-@pytest.mark.parametrize("P,M,N", [(5000, 256, 256), (4099, 128, 256), (3001, 256, 63), (777, 128, 27), (2500, 3, 128), (1999, 1, 256), (11, 256, 256)])
+@pytest.mark.parametrize("P,M,N", [(5000, 256, 256), (4099, 128, 256), (3001, 256, 63), (777, 128, 27), (2500, 3, 128), (1999, 1, 256), (11, 256, 256), (1237, 192, 160), (1, 256, 256)])
 def test_wgrad_product_vs_float64(P, M, N):
     """One weight-gradient product on its own (mi_nerf_wgrad_product) against a float64 matmul: every operand shape of the
     network, point counts that are not multiples of the 12-row load group."""
