@@ -48,6 +48,8 @@ POINTS_PER_RAY = SC + (SC + NF)          # 64 coarse + 192 fine network evaluati
 FLOP_PER_RAY = FLOP_PER_POINT * POINTS_PER_RAY          # 303,824,896
 PEAK_F32_MFMA_TFLOPS = 157.3             # MI355X_MICROARCH.md: 256 CU x 256 FLOP/clk x 2.4 GHz
 PEAK_BF16_MFMA_TFLOPS = 2500.0           # dense bf16 MFMA peak (the headline 5 PF figure includes 2:1 sparsity)
+LDS_DMA_CHIP_TBPS = 6.4                  # chip-wide L2 -> LDS fill rate, default cache policy (MI355X_MICROARCH.md, "ldsdma-fill")
+BF16_POINTS_PER_PASS = 256               # mlp_bf16.hip: a workgroup takes 4 waves x 64 points through one pass of the weight stream
 KERNEL_SOURCES = ("mlp_fp32.hip", "mlp_core.h", "layout.h", "common.h")
 
 
@@ -116,6 +118,19 @@ def kernel_build_id() -> str:
         with open(os.path.join(ROOT, "nerf_pytorch_paeng_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
+
+
+def bf16_stream(blob, n_points: int, kernel_ms: float) -> dict:
+    """The second bound of the bf16 kernel: every workgroup pulls the whole bf16 weight stream from L2 into LDS once per
+    BF16_POINTS_PER_PASS points (the register file holds no more), so a launch moves passes x stream bytes through the L2 -> LDS path."""
+    import numpy as np
+    hdr = blob[:64].cpu().numpy().view(np.uint32)
+    stream_bytes = int(hdr[8])
+    passes = (n_points + BF16_POINTS_PER_PASS - 1) // BF16_POINTS_PER_PASS
+    gb = passes * stream_bytes / 1e9
+    tbps = gb / kernel_ms
+    return {"bytes_per_pass": stream_bytes, "passes": passes, "GB_per_launch": round(gb, 3), "l2_to_lds_TBps": round(tbps, 2),
+            "chip_lds_dma_rate_TBps": LDS_DMA_CHIP_TBPS, "frac_of_lds_dma_rate": round(tbps / LDS_DMA_CHIP_TBPS, 3)}
 
 
 def worker(args) -> None:
@@ -252,6 +267,7 @@ def worker(args) -> None:
     if args.bf16:
         roofline["peak_is"] = "dense bf16 MFMA"
         roofline["frac_of_f32_mfma_peak"] = round(achieved / PEAK_F32_MFMA_TFLOPS, 4)
+        roofline["weight_stream"] = bf16_stream(blobs[1], main.n * (SC + NF), k_ms)
 
     # ---- BASELINE config #5 on the same shard: the bf16 MFMA variant, timed like the headline and held against the fp32 outputs ----
     bf16_leg = None
@@ -289,6 +305,7 @@ def worker(args) -> None:
                     "fine_kernel_ms": round(k16, 4),
                     "fine_kernel_TFLOPs": round(k_flop / (k16 * 1e-3) / 1e12, 1),
                     "fine_kernel_frac_of_bf16_peak": round(k_flop / (k16 * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
+                    "weight_stream": bf16_stream(blobs16[1], main.n * (SC + NF), k16),
                     "psnr_rgb_c_vs_fp32_dB": round(psnr(out16[0], ref32[0]), 2), "psnr_rgb_f_vs_fp32_dB": round(psnr(out16[2], ref32[2]), 2),
                     "max_abs_rgb_f_diff": round(float((out16[2] - ref32[2]).abs().max()), 5)}
         del raw16, zf16
