@@ -250,11 +250,15 @@ __device__ __forceinline__ void mask_pack_chunk(const float (&h)[NB], int q, uns
     mask_bits_chunk(h, q, bits);
     mask_merge_chunk(bits, q, mw);
 }
-// register 4q+e masked by its bit: move the bit to the sign, smear it to 0 / ~0 and AND the float's bits
+// register 4q+e masked by its bit: extract the bit sign-extended (0 / ~0) and AND the float's bits -- two VALU per value, pinned:
+// from the C++ shifts hipcc builds and + compare + select (three; VALU work beside fp32 MFMAs is paid in MFMA cycles).
 template <int NW>
 __device__ __forceinline__ float mask_apply(float v, int q, int e, const unsigned (&mw)[NW]) {
-    const int m = ((int)(mw[q >> 3] << (4 * (q & 7) + e))) >> 31;
-    return __uint_as_float(__float_as_uint(v) & (unsigned)m);
+    int m;
+    float r;
+    asm volatile("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(mw[q >> 3]), "s"(31 - (4 * (q & 7) + e)));
+    asm volatile("v_and_b32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(m));
+    return r;
 }
 
 __device__ __forceinline__ float xhalf_sum(float v) { return v + __shfl_xor(v, 32, 64); }
