@@ -106,7 +106,9 @@ int mi_nerf_sample_pdf(const float* bins_dev, const float* weights_dev, int64_t 
                        const float* u_dev, float* samples_dev, void* stream);
 /* a7  fine branch of pre_process                                          nerf_process.py:62-67
  * z_c [n, Sc] (sorted), weights_c [n, Sc] -> z_fine [n, Sc+Nf] = sort(cat(z_c, sample_pdf(mid(z_c),
- * weights_c[1:-1], Nf))); z_samples_dev (optional, [n, Nf]) receives the unsorted new samples. */
+ * weights_c[1:-1], Nf))); z_samples_dev (optional, [n, Nf]) receives the unsorted new samples.
+ * NaN depths (NaN weights) are placed last, as torch.sort does.  Size limit (one wave's LDS slice): 2 (Sc - 1) + the next
+ * power of two >= Sc + Nf must not exceed 4096 floats; larger sample counts are refused with MI_NERF_EINVAL. */
 int mi_nerf_fine_z(const float* z_c_dev, const float* weights_c_dev, int64_t n, int Sc, int Nf, int det,
                    const float* u_dev, float* z_fine_dev, float* z_samples_dev, void* stream);
 
