@@ -184,6 +184,13 @@ int mi_nerf_pack_weights_bwd(const mi_nerf_net* net, const mi_nerf_params* param
  * blob (mi_nerf_packed_bytes_bwd).  map_len = blob bytes / 4 entries; entry = 1 + flat index, 0 = constant zero. */
 int mi_nerf_pack_map(const mi_nerf_net* net, int kind, int32_t* map_host, size_t map_len);
 int mi_nerf_pack_apply(const int32_t* map_dev, const float* flat_params_dev, size_t blob_bytes, void* blob_dev, void* stream);
+/* The same for the bf16 blob (mi_nerf_packed_bytes_bf16): one map entry per bf16 stream element followed by one per fp32
+ * side-table float (mi_nerf_pack_map_bf16_len entries); the apply kernel rounds the stream to bf16 (nearest even) and writes
+ * the blob header.  A model whose parameters live on the device is packed without a host round trip (weights.py). */
+size_t mi_nerf_pack_map_bf16_len(const mi_nerf_net* net);
+int mi_nerf_pack_map_bf16(const mi_nerf_net* net, int32_t* map_host, size_t map_len);
+int mi_nerf_pack_apply_bf16(const mi_nerf_net* net, const int32_t* map_dev, const float* flat_params_dev, void* blob_dev,
+                            size_t blob_bytes, void* stream);
 
 /* Activation stash written by the training forward and the scratch the backward needs (byte offsets). */
 typedef struct mi_nerf_train_layout {

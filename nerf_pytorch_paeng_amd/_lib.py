@@ -82,6 +82,9 @@ SIGNATURES = {
     "mi_nerf_pack_weights_bwd": (_I, [_NETP, C.POINTER(Params), _P, _SZ]),
     "mi_nerf_pack_map": (_I, [_NETP, _I, _P, _SZ]),
     "mi_nerf_pack_apply": (_I, [_P, _P, _SZ, _P, _P]),
+    "mi_nerf_pack_map_bf16_len": (_SZ, [_NETP]),
+    "mi_nerf_pack_map_bf16": (_I, [_NETP, _P, _SZ]),
+    "mi_nerf_pack_apply_bf16": (_I, [_NETP, _P, _P, _P, _SZ, _P]),
     "mi_nerf_train_layout_query": (_I, [_NETP, _I64, _I, C.POINTER(TrainLayout)]),
     "mi_nerf_mlp_rays_train": (_I, [_NETP, _P, _P, _P, _I64, _I, _P, _P, _SZ, _P]),
     "mi_nerf_mlp_backward": (_I, [_NETP, _P, _P, _P, _P, _I64, _I, _P, _P, _P, _SZ, _P, _I, _P]),

@@ -46,6 +46,9 @@ int ensure_lds_opt_in(LdsOptIn& state, const void* kernel) {
 int pack_fp32(const mi_nerf_net*, const mi_nerf_params*, void*, size_t);
 int pack_bf16(const mi_nerf_net*, const mi_nerf_params*, void*, size_t);
 size_t packed_bytes_bf16(const mi_nerf_net*);
+size_t pack_map_bf16_len(const mi_nerf_net*);
+int pack_map_bf16(const mi_nerf_net*, int32_t*, size_t);
+int pack_apply_bf16(const mi_nerf_net*, const int32_t*, const float*, void*, size_t, hipStream_t);
 int mlp_rays_fp32(const mi_nerf_net*, const void*, const float*, const float*, int64_t, int, float*, hipStream_t);
 int mlp_embedded_fp32(const mi_nerf_net*, const void*, const float*, int64_t, float*, hipStream_t);
 int mlp_rays_bf16(const mi_nerf_net*, const void*, const float*, const float*, int64_t, int, float*, hipStream_t);
@@ -226,6 +229,18 @@ int mi_nerf_pack_weights_bwd(const mi_nerf_net* net, const mi_nerf_params* param
 int mi_nerf_pack_map(const mi_nerf_net* net, int kind, int32_t* map_host, size_t map_len) {
     if (int rc = check_net_basic(net)) return rc;
     return pack_map(net, kind, map_host, map_len);
+}
+size_t mi_nerf_pack_map_bf16_len(const mi_nerf_net* net) {
+    if (!net) return 0;
+    return pack_map_bf16_len(net);
+}
+int mi_nerf_pack_map_bf16(const mi_nerf_net* net, int32_t* map_host, size_t map_len) {
+    MN_CHECK_ARG(net && map_host, "NULL pointer");
+    return pack_map_bf16(net, map_host, map_len);
+}
+int mi_nerf_pack_apply_bf16(const mi_nerf_net* net, const int32_t* map_dev, const float* flat_dev, void* blob_dev, size_t blob_bytes, void* st) {
+    MN_CHECK_ARG(net, "net is NULL");
+    return pack_apply_bf16(net, map_dev, flat_dev, blob_dev, blob_bytes, (hipStream_t)st);
 }
 int mi_nerf_pack_apply(const int32_t* map_dev, const float* flat_dev, size_t blob_bytes, void* blob_dev, void* st) {
     return pack_apply(map_dev, flat_dev, blob_bytes, blob_dev, (hipStream_t)st);

@@ -108,14 +108,21 @@ static inline uint16_t f32_to_bf16_rne(float x) {
     return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
 }
 
+// The stream is emitted either as bf16 (the blob) or as the float itself (the gather map of the device-side packer, built by
+// running this packer over parameters whose values are their own flat index + 1).
+template <typename T> static inline T stream_elem(float x);
+template <> inline uint16_t stream_elem<uint16_t>(float x) { return f32_to_bf16_rne(x); }
+template <> inline float stream_elem<float>(float x) { return x; }
+
 // One quad: the A fragment of output rows row0..row0+15 for the 32 input columns cols[q*8 + j] (-1: zero).
 // rowmap (optional, 16 entries): weight-matrix row feeding output row i of the tile, -1: zero row.
-static void emit_quad(std::vector<uint16_t>& st, const float* Wm, int n_out, int n_in, int row0, const int* rowmap, const int* cols) {
+template <typename T>
+static void emit_quad(std::vector<T>& st, const float* Wm, int n_out, int n_in, int row0, const int* rowmap, const int* cols) {
     for (int lane = 0; lane < 64; ++lane)
         for (int j = 0; j < 8; ++j) {
             const int col = cols[(lane >> 4) * 8 + j];
             const int n = rowmap ? rowmap[lane & 15] : row0 + (lane & 15);
-            st.push_back((col >= 0 && n >= 0 && n < n_out) ? f32_to_bf16_rne(Wm[(size_t)n * n_in + col]) : (uint16_t)0);
+            st.push_back((col >= 0 && n >= 0 && n < n_out) ? stream_elem<T>(Wm[(size_t)n * n_in + col]) : (T)0);
         }
 }
 static std::vector<int> enc_cols32(int L, int base) {
@@ -133,10 +140,11 @@ static std::vector<int> act_cols32(int W, int base) {
     return c;
 }
 // a layer in output-tile-major order: for every tile, all its k-steps
-static void emit_layer(std::vector<uint16_t>& st, const float* Wm, int n_out, int n_in, int NT, const std::vector<int>& cols) {
+template <typename T>
+static void emit_layer(std::vector<T>& st, const float* Wm, int n_out, int n_in, int NT, const std::vector<int>& cols) {
     const int KS = (int)cols.size() / KF;
-    for (int T = 0; T < NT; ++T)
-        for (int ks = 0; ks < KS; ++ks) emit_quad(st, Wm, n_out, n_in, MT * T, nullptr, cols.data() + KF * ks);
+    for (int tile = 0; tile < NT; ++tile)
+        for (int ks = 0; ks < KS; ++ks) emit_quad(st, Wm, n_out, n_in, MT * tile, nullptr, cols.data() + KF * ks);
 }
 
 static int check_net_bf16(const mi_nerf_net* net) {
@@ -151,14 +159,12 @@ size_t packed_bytes_bf16(const mi_nerf_net* net) {
     return make_layout_bf16(net->D, net->W, net->skip, net->L_x, net->L_d).total_bytes;
 }
 
-int pack_bf16(const mi_nerf_net* net, const mi_nerf_params* p, void* blob, size_t blob_bytes) {
-    if (int rc = check_net_bf16(net)) return rc;
+// the weight stream in consumption order
+template <typename T>
+static int build_stream(const mi_nerf_net* net, const mi_nerf_params* p, const BlobLayoutBf16& L, std::vector<T>& st) {
     const int D = net->D, W = net->W, NT = W / MT;
     const int in_x = 3 + 6 * net->L_x, in_d = 3 + 6 * net->L_d;
-    const BlobLayoutBf16 L = make_layout_bf16(D, W, net->skip, net->L_x, net->L_d);
-    MN_CHECK_ARG(blob_bytes >= L.total_bytes, "blob too small: %zu < %u", blob_bytes, L.total_bytes);
-    memset(blob, 0, L.total_bytes);
-    std::vector<uint16_t> st;
+    const size_t per_quad = QUAD_BYTES / 2;
     st.reserve(L.stream_bytes / 2);
     emit_layer(st, p->linear_x_w[0], W, in_x, NT, enc_cols32(net->L_x, 0));
     for (int l = 1; l < D; ++l) {
@@ -184,14 +190,13 @@ int pack_bf16(const mi_nerf_net* net, const mi_nerf_params* p, void* blob, size_
         for (int i = 0; i < MT; ++i) rowmap[i] = (i < 3) ? i : -1;      // output rows 0..2 <- linear_color rows 0..2
         for (int ks = 0; ks < W / 2 / KF; ++ks) emit_quad(st, p->linear_color_w, 3, W / 2, 0, rowmap, act.data() + KF * ks);
     }
-    st.resize(st.size() + (size_t)(TAIL_QUADS - TAIL_USED) * (QUAD_BYTES / 2), 0);
+    st.resize(st.size() + (size_t)(TAIL_QUADS - TAIL_USED) * per_quad, (T)0);
     MN_CHECK_ARG(st.size() * 2 == L.stream_bytes, "internal: bf16 stream %zu != %u", st.size() * 2, L.stream_bytes);
-    uint32_t* hdr = (uint32_t*)blob;
-    hdr[0] = BLOB_MAGIC; hdr[1] = 3; hdr[2] = D; hdr[3] = W; hdr[4] = (uint32_t)net->skip; hdr[5] = net->L_x; hdr[6] = net->L_d;
-    hdr[7] = L.stream_off; hdr[8] = L.stream_bytes; hdr[9] = L.stream_bytes; hdr[10] = L.side_off; hdr[11] = L.side_floats;
-    hdr[12] = 2;   // stream element bytes
-    memcpy((char*)blob + L.stream_off, st.data(), L.stream_bytes);
-    float* side = (float*)((char*)blob + L.side_off);
+    return MI_NERF_OK;
+}
+// the fp32 side tables
+static void fill_side(const mi_nerf_net* net, const mi_nerf_params* p, const BlobLayoutBf16& L, float* side) {
+    const int D = net->D, W = net->W, in_d = 3 + 6 * net->L_d;
     for (int l = 0; l < D; ++l) memcpy(side + L.bias_trunk + (size_t)l * W, p->linear_x_b[l], W * 4);
     memcpy(side + L.bias_feat, p->linear_feat_b, W * 4);
     memcpy(side + L.bias_d, p->linear_d_b, (W / 2) * 4);
@@ -199,6 +204,89 @@ int pack_bf16(const mi_nerf_net* net, const mi_nerf_params* p, void* blob, size_
     side[L.head_b + 3] = p->linear_density_b[0];
     for (int f = 0; f < in_d; ++f)
         for (int n = 0; n < W / 2; ++n) side[L.wdir_t + (size_t)f * (W / 2) + n] = p->linear_d_w[(size_t)n * (W + in_d) + W + f];
+}
+static void fill_header(const mi_nerf_net* net, const BlobLayoutBf16& L, uint32_t* hdr) {
+    memset(hdr, 0, HEADER_BYTES);
+    hdr[0] = BLOB_MAGIC; hdr[1] = 3; hdr[2] = net->D; hdr[3] = net->W; hdr[4] = (uint32_t)net->skip; hdr[5] = net->L_x; hdr[6] = net->L_d;
+    hdr[7] = L.stream_off; hdr[8] = L.stream_bytes; hdr[9] = L.stream_bytes; hdr[10] = L.side_off; hdr[11] = L.side_floats;
+    hdr[12] = 2;   // stream element bytes
+}
+
+int pack_bf16(const mi_nerf_net* net, const mi_nerf_params* p, void* blob, size_t blob_bytes) {
+    if (int rc = check_net_bf16(net)) return rc;
+    const BlobLayoutBf16 L = make_layout_bf16(net->D, net->W, net->skip, net->L_x, net->L_d);
+    MN_CHECK_ARG(blob_bytes >= L.total_bytes, "blob too small: %zu < %u", blob_bytes, L.total_bytes);
+    memset(blob, 0, L.total_bytes);
+    std::vector<uint16_t> st;
+    if (int rc = build_stream(net, p, L, st)) return rc;
+    fill_header(net, L, (uint32_t*)blob);
+    memcpy((char*)blob + L.stream_off, st.data(), L.stream_bytes);
+    fill_side(net, p, L, (float*)((char*)blob + L.side_off));
+    return MI_NERF_OK;
+}
+
+// Device-side packing of the bf16 blob (a model whose parameters live on the device is re-packed for every call: weights.py):
+// gather map from the flat parameter vector (mi_nerf_param_count order), one entry per stream ELEMENT followed by one per side
+// float; entry = 1 + flat index, 0 = constant zero.  Built like pack_map (pack.cpp): this packer run over index-valued parameters.
+size_t pack_map_bf16_len(const mi_nerf_net* net) {
+    if (check_net_bf16(net)) return 0;
+    const BlobLayoutBf16 L = make_layout_bf16(net->D, net->W, net->skip, net->L_x, net->L_d);
+    return (size_t)L.stream_bytes / 2 + L.side_floats;
+}
+int pack_map_bf16(const mi_nerf_net* net, int32_t* map, size_t map_len) {
+    if (int rc = check_net_bf16(net)) return rc;
+    const int D = net->D, W = net->W;
+    const BlobLayoutBf16 L = make_layout_bf16(D, W, net->skip, net->L_x, net->L_d);
+    const ParamOffsets po = make_param_offsets(D, W, net->skip, net->L_x, net->L_d);
+    MN_CHECK_ARG(po.total < (1u << 24), "network too large for the index map (%u parameters)", po.total);
+    const size_t n_stream = (size_t)L.stream_bytes / 2;
+    MN_CHECK_ARG(map && map_len >= n_stream + L.side_floats, "map too small: %zu entries for %zu", map_len, n_stream + L.side_floats);
+    std::vector<float> flat(po.total);
+    for (uint32_t i = 0; i < po.total; ++i) flat[i] = (float)(i + 1);
+    std::vector<const float*> wx(D), bx(D);
+    for (int l = 0; l < D; ++l) { wx[l] = flat.data() + po.w_x[l]; bx[l] = flat.data() + po.b_x[l]; }
+    mi_nerf_params p{};
+    p.linear_x_w = wx.data(); p.linear_x_b = bx.data();
+    p.linear_density_w = flat.data() + po.w_dens; p.linear_density_b = flat.data() + po.b_dens;
+    p.linear_feat_w = flat.data() + po.w_feat; p.linear_feat_b = flat.data() + po.b_feat;
+    p.linear_d_w = flat.data() + po.w_d; p.linear_d_b = flat.data() + po.b_d;
+    p.linear_color_w = flat.data() + po.w_color; p.linear_color_b = flat.data() + po.b_color;
+    std::vector<float> st;
+    if (int rc = build_stream(net, &p, L, st)) return rc;
+    std::vector<float> side(L.side_floats, 0.0f);
+    fill_side(net, &p, L, side.data());
+    for (size_t i = 0; i < n_stream; ++i) map[i] = (int32_t)st[i];
+    for (size_t i = 0; i < L.side_floats; ++i) map[n_stream + i] = (int32_t)side[i];
+    return MI_NERF_OK;
+}
+
+struct HeaderWords { uint32_t w[HEADER_BYTES / 4]; };
+__global__ __launch_bounds__(256) void pack_apply_bf16_kernel(const int32_t* __restrict__ map, const float* __restrict__ flat, unsigned n_stream,
+                                                               unsigned n_side, unsigned stream_off, unsigned side_off, HeaderWords hdr,
+                                                               char* __restrict__ blob) {
+    const unsigned i = blockIdx.x * 256 + threadIdx.x;
+    if (i < HEADER_BYTES / 4) ((uint32_t*)blob)[i] = hdr.w[i];
+    if (i < n_stream) {
+        const int32_t m = map[i];
+        unsigned u = m ? __float_as_uint(flat[m - 1]) : 0u;
+        u = ((u & 0x7FFFFFFFu) > 0x7F800000u) ? ((u >> 16) | 0x40u) : ((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);      // f32_to_bf16_rne
+        ((uint16_t*)(blob + stream_off))[i] = (uint16_t)u;
+    } else if (i < n_stream + n_side) {
+        const int32_t m = map[i];
+        ((float*)(blob + side_off))[i - n_stream] = m ? flat[m - 1] : 0.0f;
+    }
+}
+int pack_apply_bf16(const mi_nerf_net* net, const int32_t* map_dev, const float* flat_dev, void* blob_dev, size_t blob_bytes, hipStream_t st) {
+    if (int rc = check_net_bf16(net)) return rc;
+    const BlobLayoutBf16 L = make_layout_bf16(net->D, net->W, net->skip, net->L_x, net->L_d);
+    MN_CHECK_ARG(map_dev && flat_dev && blob_dev, "NULL device pointer");
+    MN_CHECK_ARG(blob_bytes >= L.total_bytes && ((uintptr_t)blob_dev & 15) == 0, "blob too small (%zu < %u) or not 16-byte aligned", blob_bytes, L.total_bytes);
+    HeaderWords h;
+    fill_header(net, L, h.w);
+    const unsigned n_stream = L.stream_bytes / 2, total = n_stream + L.side_floats;
+    hipLaunchKernelGGL(pack_apply_bf16_kernel, dim3((total + 255) / 256), dim3(256), 0, st, map_dev, flat_dev, n_stream, L.side_floats, L.stream_off,
+                       L.side_off, h, (char*)blob_dev);
+    MN_LAUNCH_CHECK("pack_apply_bf16_kernel");
     return MI_NERF_OK;
 }
 

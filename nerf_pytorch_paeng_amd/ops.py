@@ -313,6 +313,27 @@ def pack_apply(map_dev: torch.Tensor, flat: torch.Tensor, out: Optional[torch.Te
     return out
 
 
+def pack_map_bf16(net: Net) -> torch.Tensor:
+    """Gather map (CPU int32) from the flat parameter vector to the bf16 blob: stream elements, then side-table floats."""
+    n = lib().mi_nerf_pack_map_bf16_len(C.byref(net))
+    if n == 0:
+        check(1, "mi_nerf_pack_map_bf16_len")
+    m = torch.empty(n, dtype=torch.int32)
+    check(lib().mi_nerf_pack_map_bf16(C.byref(net), m.data_ptr(), m.numel()), "mi_nerf_pack_map_bf16")
+    return m
+
+
+def pack_apply_bf16(net: Net, map_dev: torch.Tensor, flat: torch.Tensor) -> torch.Tensor:
+    """Device-side pack of the bf16 blob (uint8) from the flat parameter vector."""
+    dev = flat.device
+    nbytes = lib().mi_nerf_packed_bytes_bf16(C.byref(net))
+    out = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    with _guard(dev):
+        check(lib().mi_nerf_pack_apply_bf16(C.byref(net), dev_ptr(map_dev, "map", torch.int32), dev_ptr(flat, "flat"), dev_ptr(out, "blob", torch.uint8, 16),
+                                            nbytes, stream_ptr(dev)), "mi_nerf_pack_apply_bf16")
+    return out
+
+
 def mlp_rays_train(net: Net, packed: torch.Tensor, rays: torch.Tensor, z: torch.Tensor, stash: Optional[torch.Tensor] = None):
     """Training forward: raw [n,S,4] plus the activation stash the backward reads."""
     n, S = z.shape

@@ -8,7 +8,6 @@ shapes, packs both networks into the kernels' streaming layout and keeps the blo
 """
 from __future__ import annotations
 
-import weakref
 from typing import Dict, Optional, Tuple
 
 import numpy as np
@@ -50,7 +49,7 @@ class PackedNeRF:
         self.net, self.coarse, self.fine = net, coarse, fine
         self._bf16: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
         self._sd = None
-        self._sd_source = None
+        self._flat: Optional[Tuple[torch.Tensor, torch.Tensor]] = None      # device-resident flat parameter vectors (nn.Module source)
 
     @property
     def device(self) -> torch.device:
@@ -71,16 +70,20 @@ class PackedNeRF:
         return self
 
     def bf16(self) -> Tuple[torch.Tensor, torch.Tensor]:
-        """bf16-stream blobs for the bf16 MFMA variant (packed lazily, on the host; for an nn.Module source from the parameter
-        values at the time this PackedNeRF was made -- packed_for() makes a new one per call)."""
+        """bf16-stream blobs for the bf16 MFMA variant, packed lazily: on the device from the flat parameter vectors when this
+        PackedNeRF came from an nn.Module (packed_for() makes a new one per call, so a host round trip here would be paid per
+        call), on the host from the kept state dict otherwise (once)."""
         if self._bf16 is None:
-            src = self._sd_source() if self._sd_source is not None else None
-            if self._sd is None and src is not None:
-                self._sd = {k: v.detach().cpu().numpy() for k, v in src.state_dict().items() if k.startswith("model_")}
-            if self._sd is None:
-                raise MiNerfError("bf16 packing needs the state dict (keep_state=True)")
-            self._bf16 = (ops.pack_module(self._sd, "model_coarse.", self.net, bf16=True).to(self.device),
-                          ops.pack_module(self._sd, "model_fine.", self.net, bf16=True).to(self.device))
+            if self._flat is not None:
+                key = (tuple(getattr(self.net, f) for f, _ in Net._fields_), str(self.device))
+                if key not in _maps_bf16:
+                    _maps_bf16[key] = ops.pack_map_bf16(self.net).to(self.device)
+                self._bf16 = tuple(ops.pack_apply_bf16(self.net, _maps_bf16[key], flat) for flat in self._flat)
+            else:
+                if self._sd is None:
+                    raise MiNerfError("bf16 packing needs the state dict (keep_state=True)")
+                self._bf16 = (ops.pack_module(self._sd, "model_coarse.", self.net, bf16=True).to(self.device),
+                              ops.pack_module(self._sd, "model_fine.", self.net, bf16=True).to(self.device))
         return self._bf16
 
     def blob(self, is_fine: bool) -> torch.Tensor:
@@ -112,6 +115,7 @@ def packed_for(model, device=None) -> PackedNeRF:
 
 # gather maps per network shape (built once by the host packer, kept on the device)
 _maps: Dict[tuple, torch.Tensor] = {}
+_maps_bf16: Dict[tuple, torch.Tensor] = {}
 
 
 def _pack_module_on_device(model: torch.nn.Module, device: torch.device) -> PackedNeRF:
@@ -125,7 +129,8 @@ def _pack_module_on_device(model: torch.nn.Module, device: torch.device) -> Pack
     key = (tuple(getattr(net, f) for f, _ in Net._fields_), str(device))
     if key not in _maps:
         _maps[key] = ops.pack_map(net, False).to(device)
-    blobs = [ops.pack_apply(_maps[key], ops.flatten_params(sd, prefix, net, device)) for prefix in ("model_coarse.", "model_fine.")]
+    flats = [ops.flatten_params(sd, prefix, net, device) for prefix in ("model_coarse.", "model_fine.")]
+    blobs = [ops.pack_apply(_maps[key], flat) for flat in flats]
     packed = PackedNeRF(net, blobs[0], blobs[1])
-    packed._sd_source = weakref.ref(model)   # the bf16 variant is packed on the host, lazily; weak: the cache is keyed by the module
+    packed._flat = (flats[0], flats[1])      # the bf16 variant is packed from these, lazily, on the device
     return packed

@@ -140,6 +140,34 @@ def test_device_pack_matches_host_pack():
         assert torch.equal(host[1024:], dev[1024:])            # everything but the (unused on device) header
 
 
+def test_device_bf16_pack_matches_host_pack_and_serves_module_models():
+    """The bf16 blob packed on the device from the flat parameter vector equals the host packer's, header included; an nn.Module
+    model rendered with bf16=True goes through it (no host round trip per call) and gives the PackedNeRF result."""
+    from types import SimpleNamespace
+    from nerf_pytorch_paeng_amd import nerf_process as NP, weights
+    from nerf_pytorch_paeng_amd.model import NeRF
+    net = ops.make_net(8, 256, 4)
+    sd = synthetic.make_state_dict(3, 8, 256)
+    m = ops.pack_map_bf16(net).to(DEV)
+    for prefix in ("model_coarse.", "model_fine."):
+        host = ops.pack_module(sd, prefix, net, bf16=True)
+        dev = ops.pack_apply_bf16(net, m, ops.flatten_params(sd, prefix, net, DEV)).cpu()
+        assert torch.equal(host, dev)
+    model = NeRF(8, 256, 63, 27).to(DEV)
+    model.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+    packed = weights.PackedNeRF.from_state_dict(sd, DEV)
+    opts = SimpleNamespace(near=2.0, far=6.0, N_samples_c=16, N_samples_f=16, perturb=1.0, chunk_rays=4096, chunk_pts=524288,
+                           data_type="blender", gpu_ids=[0], rank=0)
+    K, H, Wd = synthetic.lego_camera()
+    pix = torch.from_numpy(synthetic.pixel_batch(H, Wd, 128, 1)).to(DEV)
+    o, d = ops.make_o_d_pixels(Wd, H, K, synthetic.pose_spherical(30.0, -30.0, 4.0), pix)
+    with torch.no_grad():
+        a = NP.batchify_rays_and_render_by_chunk(o, d, model, None, H, Wd, K, opts, seed=5, bf16=True)
+        b = NP.batchify_rays_and_render_by_chunk(o, d, packed, None, H, Wd, K, opts, seed=5, bf16=True)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+
+
 # ---------------------------------------------------------------------------------------------------
 # whole training step through the drop-in surface (train.py:53-70)
 # ---------------------------------------------------------------------------------------------------

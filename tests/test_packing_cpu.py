@@ -204,6 +204,27 @@ def test_bf16_blob_emulation_matches_bf16_oracle(D, skip):
     np.testing.assert_allclose(out, ref, atol=1e-9, rtol=1e-9)
 
 
+@pytest.mark.parametrize("D,skip", [(8, 4), (4, -1)])
+def test_bf16_pack_map_reproduces_the_host_blob(D, skip):
+    """The gather map of the device-side bf16 packer (mi_nerf_pack_map_bf16), applied here in numpy with the same rounding, must
+    give the host packer's blob bit for bit: stream elements rounded to bf16, fp32 side tables."""
+    from tests.blob_emulator_bf16 import bf16_round
+    net = ops.make_net(D, 256, skip)
+    sd = synthetic.make_state_dict(11, D, 256, skips=(skip,) if skip >= 0 else ())
+    blob = ops.pack_module(sd, "model_fine.", net, bf16=True).numpy()
+    hdr = np.frombuffer(blob[:64].tobytes(), dtype=np.uint32)
+    so, sb, sdo, sf = int(hdr[7]), int(hdr[8]), int(hdr[10]), int(hdr[11])
+    m = ops.pack_map_bf16(net).numpy()
+    assert m.shape[0] == sb // 2 + sf
+    flat = ops.flatten_params(sd, "model_fine.", net).numpy()
+    src = np.where(m > 0, flat[np.maximum(m, 1) - 1], np.float32(0.0)).astype(np.float32)
+    want_stream = np.frombuffer(blob[so:so + sb].tobytes(), dtype=np.uint16)
+    got_stream = (bf16_round(src[:sb // 2]).view(np.uint32) >> 16).astype(np.uint16)
+    assert np.array_equal(got_stream, want_stream)
+    want_side = np.frombuffer(blob[sdo:sdo + 4 * sf].tobytes(), dtype=np.float32)
+    assert np.array_equal(src[sb // 2:], want_side)
+
+
 def test_bf16_kernel_owns_m0_and_the_agpr_file():
     """mlp_bf16.hip sets M0 without saving it and addresses the whole AGPR file by explicit register numbers: both are only
     sound while hipcc itself never touches M0 / an AGPR in that kernel.  Disassemble the object and check."""
