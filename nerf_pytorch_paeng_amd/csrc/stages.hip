@@ -226,15 +226,12 @@ __device__ __forceinline__ float wave_excl_sum(float v, int lane) {
 // ------------------------------------------------------------------------------------------------
 // alpha compositing: one wavefront per ray, lane l owns samples [l*C, (l+1)*C)
 // ------------------------------------------------------------------------------------------------
+// One ray (this wave).  w_lds (optional): the weights also go to this LDS array.
 template <int C>
-__global__ __launch_bounds__(256) void composite_kernel(const float* __restrict__ raw, const float* __restrict__ z,
-                                                         const float* __restrict__ rays, int ray_stride, long long n, int S,
-                                                         float* __restrict__ rgb_o, float* __restrict__ disp_o,
-                                                         float* __restrict__ acc_o, float* __restrict__ w_o,
-                                                         float* __restrict__ depth_o) {
-    const int lane = threadIdx.x & 63;
-    const long long ray = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (ray >= n) return;
+__device__ __forceinline__ void composite_ray(const float* __restrict__ raw, const float* __restrict__ z, const float* __restrict__ rays,
+                                              int ray_stride, long long ray, int S, int lane, float* __restrict__ rgb_o,
+                                              float* __restrict__ disp_o, float* __restrict__ acc_o, float* __restrict__ w_o,
+                                              float* __restrict__ depth_o, float* w_lds) {
     const float* dp = rays + ray * ray_stride + (ray_stride == 6 ? 3 : 0);
     const float dx = dp[0], dy = dp[1], dz = dp[2];
     const float dnorm = __builtin_sqrtf(dx * dx + dy * dy + dz * dz);     // nerf_process.py:101
@@ -270,6 +267,7 @@ __global__ __launch_bounds__(256) void composite_kernel(const float* __restrict_
         const float w = alpha[c] * T;                                      // :111
         if (s < S) {
             if (w_o) w_o[ray * S + s] = w;
+            if (w_lds) w_lds[s] = w;
             sw += w; sr += w * cr[c]; sg += w * cg[c]; sb += w * cb[c]; sd += w * zv[c];
         }
         T *= (1.0f - alpha[c] + 1e-10f);
@@ -287,6 +285,18 @@ __global__ __launch_bounds__(256) void composite_kernel(const float* __restrict_
         if (acc_o) acc_o[ray] = sw;
         if (depth_o) depth_o[ray] = sd;
     }
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void composite_kernel(const float* __restrict__ raw, const float* __restrict__ z,
+                                                         const float* __restrict__ rays, int ray_stride, long long n, int S,
+                                                         float* __restrict__ rgb_o, float* __restrict__ disp_o,
+                                                         float* __restrict__ acc_o, float* __restrict__ w_o,
+                                                         float* __restrict__ depth_o) {
+    const int lane = threadIdx.x & 63;
+    const long long ray = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= n) return;
+    composite_ray<C>(raw, z, rays, ray_stride, ray, S, lane, rgb_o, disp_o, acc_o, w_o, depth_o, nullptr);
 }
 
 // exclusive SUFFIX sum across the 64 lanes (sum of the lanes above this one), Kogge-Stone on __shfl_down
@@ -447,21 +457,18 @@ __global__ __launch_bounds__(256) void sample_pdf_kernel(const float* __restrict
 }
 
 // fine branch: bins = mid(z_c), weights = weights_c[1:-1], then sort(cat(z_c, samples))   (:63-67)
-__global__ __launch_bounds__(256) void fine_z_kernel(const float* __restrict__ z_c, const float* __restrict__ w_c, long long n,
-                                                      int Sc, int Nf, int n2, int det, const float* __restrict__ u,
-                                                      float* __restrict__ z_f, float* __restrict__ z_samp) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const long long ray = (long long)blockIdx.x * 4 + wv;
-    if (ray >= n) return;
+// wr: this ray's Sc coarse weights (global or LDS); lds: this wave's slice of 2 (Sc - 1) + n2 floats.
+__device__ __forceinline__ void fine_z_ray(const float* __restrict__ z_c, const float* wr, long long ray, int Sc, int Nf, int n2, int det,
+                                           const float* __restrict__ u, float* __restrict__ z_f, float* __restrict__ z_samp, float* lds,
+                                           int lane) {
     const int B = Sc - 1, St = Sc + Nf;
-    float* cdf = lds + wv * (2 * B + n2);                   // n2: Sc + Nf rounded up to a power of two (the sort network)
+    float* cdf = lds;                                       // n2: Sc + Nf rounded up to a power of two (the sort network)
     float* bn = cdf + B;
     float* all = bn + B;
     const float* zr = z_c + ray * Sc;
     for (int k = lane; k < Sc; k += 64) all[k] = zr[k];
     for (int k = lane; k < B; k += 64) bn[k] = 0.5f * (zr[k + 1] + zr[k]);                 // :63
-    build_cdf(w_c + ray * Sc + 1, Sc - 2, cdf, lane);                                       // weights[..., 1:-1]
+    build_cdf(wr + 1, Sc - 2, cdf, lane);                                                   // weights[..., 1:-1]
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     for (int j = lane; j < Nf; j += 64) {
@@ -506,6 +513,16 @@ __global__ __launch_bounds__(256) void fine_z_kernel(const float* __restrict__ z
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
     for (int e = lane; e < St; e += 64) z_f[ray * St + e] = e < St - n_nan ? all[e] : __builtin_nanf("");
+}
+
+__global__ __launch_bounds__(256) void fine_z_kernel(const float* __restrict__ z_c, const float* __restrict__ w_c, long long n,
+                                                      int Sc, int Nf, int n2, int det, const float* __restrict__ u,
+                                                      float* __restrict__ z_f, float* __restrict__ z_samp) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long long ray = (long long)blockIdx.x * 4 + wv;
+    if (ray >= n) return;
+    fine_z_ray(z_c, w_c + ray * Sc, ray, Sc, Nf, n2, det, u, z_f, z_samp, lds + wv * (2 * (Sc - 1) + n2), lane);
 }
 
 // ------------------------------------------------------------------------------------------------
