@@ -402,7 +402,7 @@ def mlp_embedded_backward(net: Net, packed: torch.Tensor, packed_bwd: torch.Tens
 
 def wgrad_product(delta: torch.Tensor, M: int, x: torch.Tensor, N: int, P: int, want_bias: bool = True, iters: int = 1, timed: bool = False):
     """out[M,N] = delta[:P,:M]^T x[:P,:N] (+ bias[M] = column sums of delta) with the backward pass's own kernels.
-    ``delta`` / ``x`` are 2-D row-major with at least P rows (wide operands: 60 rows of slack past P).  Returns
+    ``delta`` / ``x`` are 2-D row-major with at least P rows (nothing past row P - 1 is read).  Returns
     (out, bias, avg_ms) -- avg_ms only when ``timed``."""
     dev = delta.device
     if delta.dim() != 2 or x.dim() != 2 or delta.shape[0] < P or x.shape[0] < P or delta.shape[1] < M or x.shape[1] < N:

@@ -319,6 +319,30 @@ def test_wgrad_product_vs_float64(P, M, N):
     assert rel_err(bias, d[:P, :M].double().sum(0).float()) < 1e-5
 
 
+def test_wgrad_product_beyond_4GiB_operands():
+    """Operands larger than 4 GiB (the point count of a MAX_TRAIN_RAYS slab: 16384 rays x 256 samples x 1 KiB rows): the kernels
+    rebase their buffer descriptors per 12-row group, so byte offsets never need more than 32 bits.  Rows are drawn from a short
+    cycle so that the expected product is cheap: sum_p d[p]^T x[p] = sum over the cycle, weighted by how often each row occurs."""
+    P, M, N, cyc = 4_300_001, 256, 256, 977                       # P * 1 KiB > 4 GiB; 977 prime: groups and slices see every phase
+    g = torch.Generator().manual_seed(7)
+    dc = torch.randn(cyc, M, generator=g).to(DEV)
+    xc = torch.randn(cyc, N, generator=g).to(DEV)
+    idx = torch.arange(P, device=DEV) % cyc
+    d, x = dc[idx], xc[idx]                                       # [P, 256] each, 4.4 GB
+    counts = torch.bincount(idx, minlength=cyc).double()
+    want = (dc.double() * counts[:, None]).T @ xc.double()
+    out, bias, _ = ops.wgrad_product(d, M, x, N, P)
+    assert rel_err(out, want.float()) < 5e-5, rel_err(out, want.float())
+    assert rel_err(bias, (dc.double() * counts[:, None]).sum(0).float()) < 5e-5
+    # the far end alone (rows past the 4 GiB mark must be the ones read, not an alias of the start)
+    d[: P - 1000] = 0
+    out2, _, _ = ops.wgrad_product(d, M, x, N, P)
+    tail_idx = idx[P - 1000:]
+    want2 = dc[tail_idx].double().T @ xc[tail_idx].double()
+    assert rel_err(out2, want2.float()) < 1e-5
+    del d, x
+
+
 def test_training_slabs_accumulate_like_one_node(monkeypatch):
     """Rays beyond MAX_TRAIN_RAYS are rendered as several autograd nodes; the parameter gradients must equal the
     single-node ones (jitter is keyed on the global ray index, so the slabs see the same samples)."""
@@ -339,6 +363,43 @@ def test_training_slabs_accumulate_like_one_node(monkeypatch):
     assert torch.equal(rgb_one, rgb_many)
     for k in one:
         assert rel_err(many[k], one[k]) < 5e-5, k                      # same kernels; fp32 sums regrouped (scalar bias gradients cancel heavily)
+
+
+def test_largest_training_slab_matches_smaller_slabs(monkeypatch):
+    """One autograd node at MAX_TRAIN_RAYS (16384 rays x (64 + 256) points: 4.2 M fine rows, 88 GiB of stash and gradient
+    workspace, operands past the 4 GiB mark) against the same rays rendered as four nodes of 4096."""
+    from nerf_pytorch_paeng_amd import nerf_process as NP, train_path
+    free, _ = torch.cuda.mem_get_info()
+    if free < 120 * 2 ** 30:
+        pytest.skip("needs ~90 GB of device memory")
+    n = train_path.MAX_TRAIN_RAYS
+    sd, model, posenc, opts, _, _, _, _, _, _ = _train_setup(D=8, W=256, n=8, Sc=64, Nf=128, seed=2)
+    opts.N_samples_f = 192                                             # fine net: 64 + 192 = 256 points per ray
+    opts.chunk_rays = n
+    K, H, Wd = synthetic.lego_camera()
+    pix = torch.from_numpy(synthetic.pixel_batch(H, Wd, n, 3)).to(DEV)
+    o, d = ops.make_o_d_pixels(Wd, H, K, synthetic.pose_spherical(10.0, -30.0, 4.0), pix)
+    tgt = torch.rand(n, 3, generator=torch.Generator().manual_seed(4)).to(DEV)
+
+    def grads():
+        model.zero_grad(set_to_none=True)
+        rgb_c, _, rgb_f, _ = NP.batchify_rays_and_render_by_chunk(o, d, model, posenc, H, Wd, K, opts, seed=9)
+        (torch.nn.functional.mse_loss(rgb_c, tgt) + torch.nn.functional.mse_loss(rgb_f, tgt)).backward()
+        out = {k: p.grad.clone() for k, p in model.named_parameters()}, rgb_f.detach().clone()
+        torch.cuda.synchronize()
+        return out
+
+    torch.cuda.reset_peak_memory_stats()
+    one, rgb_one = grads()
+    peak = torch.cuda.max_memory_allocated() / 2 ** 30
+    torch.cuda.empty_cache()
+    monkeypatch.setattr(train_path, "MAX_TRAIN_RAYS", 4096)
+    many, rgb_many = grads()
+    assert torch.equal(rgb_one, rgb_many)
+    worst = max(rel_err(many[k], one[k]) for k in one)
+    print(f"16384-ray node vs 4 x 4096: worst gradient difference {worst:.2e}, peak memory of the single node {peak:.1f} GiB")
+    assert worst < 2e-4
+    torch.cuda.empty_cache()
 
 
 def test_training_path_refuses_what_it_does_not_support():
