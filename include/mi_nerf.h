@@ -223,8 +223,8 @@ int mi_nerf_mlp_embedded_backward(const mi_nerf_net* net, const void* packed_dev
 /* One weight-gradient product of the backward pass on its own: out[M, ldo] = delta[P, ldd]^T x[P, ldx] (first M / N columns),
  * bias[M] = column sums of delta (may be NULL) -- what autograd computes for one nn.Linear (model/NeRF.py:24-30).  The wide
  * operands of the network's own products (an operand wider than 64 columns) must be 16-byte aligned with pitches of 4 floats;
- * no operand is read outside its P rows (the load pipelines run ahead of the data, requests past row P - 1 are switched to a
- * zero buffer by address).  scratch: mi_nerf_wgrad_scratch_bytes() bytes.
+ * no operand is read outside its P rows (the load pipelines run ahead of the data through range-checked buffer loads: requests
+ * past row P - 1 return zeros without touching memory).  scratch: mi_nerf_wgrad_scratch_bytes() bytes.
  * iters launches back to back; avg_ms_out (may be NULL) = their average device time by hipEvents on `stream`
  * (bench.py's roofline leg for the training kernels; synchronises the stream when given). */
 size_t mi_nerf_wgrad_scratch_bytes(void);

@@ -4,12 +4,12 @@
 //   ndc_rays            nerf_process.py:8-28        one thread per ray
 //   fill_uniform        stand-in for torch.rand at nerf_process.py:58,162 (counter-based, shard invariant)
 //   stratified_z        nerf_process.py:42-60       one thread per sample
-//   embed               nerf_process.py:36-39,69-85 + model/PositionalEncoding.py:29-30, one thread per output
-//                       channel (coalesced 4-byte stores, the tensor is write-only traffic: 360 B/point)
+//   embed               nerf_process.py:36-39,69-85 + model/PositionalEncoding.py:29-30, one work item per (point, band) into an
+//                       LDS tile of 64 points, contiguous 16-byte stores (the tensor is write-only traffic: 360 B/point)
 //   composite           nerf_process.py:89-140      one 64-lane wavefront per ray: per-lane chunk product,
 //                       Kogge-Stone exclusive prefix product across lanes, butterfly sums
 //   sample_pdf / fine_z nerf_process.py:144-182, :62-67  one wavefront per ray: prefix-sum CDF in LDS,
-//                       branch-free upper_bound, rank sort of the merged depths
+//                       branch-free upper_bound, bitonic sort network over the merged depths
 //
 // Arithmetic follows the reference's operation order in fp32 with IEEE division and no FMA contraction
 // (the file is compiled with -ffp-contract=off); FMAs appear only where written explicitly.
