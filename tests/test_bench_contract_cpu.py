@@ -1,0 +1,35 @@
+"""The committed bench lines carry what the bench contract asks for (keys, types, consistency), so a change to bench.py that drops
+a field shows up in the CPU suite, not in the driver's parser."""
+import json
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = {"metric": str, "value": (int, float), "unit": str, "n_gpus": int, "steps": int, "warmup": int, "ms_per_step": (int, float),
+            "higher_is_better": bool, "scaling": str, "dtype": str, "data": str, "config": dict, "roofline": dict}
+
+
+@pytest.mark.parametrize("name", ["r02_bench_n1.json", "r02_bench_n1_bf16.json", "r02_bench_n1_fern.json", "r02_bench_n2_gloo_rehearsal.json"])
+def test_committed_bench_line_has_the_contract_fields(name):
+    path = os.path.join(ROOT, "profiles", name)
+    with open(path) as f:
+        lines = [l for l in f.read().splitlines() if l.startswith("{")]
+    line = json.loads(lines[-1])
+    for key, typ in REQUIRED.items():
+        assert key in line and isinstance(line[key], typ), key
+    assert "vs_baseline" in line and line["vs_baseline"] is None                  # BASELINE.md publishes no number for this metric
+    assert line["unit"] == "rays/s" and line["higher_is_better"] is True and line["scaling"] in ("strong", "weak")
+    assert "workload" in line["config"] and "model" not in line["config"]
+    roof = line["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in roof, key
+    assert roof["bound"] in ("hbm", "mfma") and 0.0 < roof["frac"] <= 1.0
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 2e-3
+    # whole-job rate: rays of the (strong-scaled) batch per step time
+    assert abs(line["value"] - 4096 / (line["ms_per_step"] * 1e-3)) / line["value"] < 2e-3
+    if line["n_gpus"] == 1 and "cpu_baseline" in line:
+        cpu = line["cpu_baseline"]
+        for key in ("value", "unit", "cores", "kind", "sample"):
+            assert key in cpu, key
+        assert cpu["kind"] in ("reference", "port")
