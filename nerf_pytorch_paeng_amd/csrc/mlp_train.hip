@@ -300,6 +300,10 @@ void wgrad_big_kernel(const WgradArgs a) {
     auto loop = [&](auto PAR) __attribute__((always_inline)) {
         long long g = 0;
         do {
+            // Keep the four waves within three groups of each other: the two waves of a pair fetch the same rows, and in the batched
+            // launch (nine products streaming through each L2) a wave that has drifted finds its partner's rows evicted -- FETCH_SIZE
+            // 18.3 GB per fine-net batch without this barrier, 14.1 GB (every operand read once) with it; 0.17 % of the step.
+            __builtin_amdgcn_s_barrier();
             step(PAR, ca, cb, fa, fb);
             step(PAR, na, nb, ca, cb);
             step(PAR, fa, fb, na, nb);
