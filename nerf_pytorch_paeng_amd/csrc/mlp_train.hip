@@ -228,7 +228,23 @@ void wgrad_big_kernel(const WgradArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 31, kh = lane >> 5;
-    const int b = blockIdx.y;                                    // product of the batch
+    // (product, slice) of this workgroup.  Workgroups are dealt round robin over the 8 XCDs (observed, not promised: it only
+    // affects speed), so consecutive linear ids would spread every product over every L2: nine operand pairs streaming through
+    // each 4 MiB L2 at once, and the rows the two waves of a pair share get evicted between their two reads (FETCH_SIZE 18.4 GB
+    // per fine-net batch for 14.1 GB of operands).  Ids that share an XCD (v % 8) are laid out consecutively instead, so an
+    // L2 sees at most two products: 15.7 GB at the same speed.  (A barrier per three groups brings it to 14.1 GB, every operand
+    // read once, but costs 0.17 % of the step: MN_WG_SYNC, not shipped.)
+#ifndef MN_WG_LINEAR
+    const unsigned nwg = gridDim.x * gridDim.y, v = blockIdx.y * gridDim.x + blockIdx.x;
+    const unsigned xcd = v & 7, slot = v >> 3;
+    const unsigned full = nwg >> 3, rem = nwg & 7;               // XCDs 0..rem-1 host full + 1 workgroups, the others full
+    const unsigned flat = xcd * full + (xcd < rem ? xcd : rem) + slot;
+    const int b = (int)(flat / gridDim.x);                       // product of the batch
+    const unsigned slice = flat - (unsigned)b * gridDim.x;
+#else
+    const int b = blockIdx.y;
+    const unsigned slice = blockIdx.x;
+#endif
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = wm * 128, n0 = wn * 128;
     const bool aok = m0 + 4 * i < a.M[b], bok = n0 + 4 * i < a.N[b];
@@ -259,7 +275,7 @@ void wgrad_big_kernel(const WgradArgs a) {
         voa[u] = aok ? (unsigned)(((2 * u + kh) * ldd + m0 + 4 * i) * 4) : 0x80000000u;
         vob[u] = bok ? (unsigned)(((2 * u + kh) * ldx + n0 + 4 * i) * 4) : 0x80000000u;
     }
-    long long req_group = blockIdx.x;                             // global index of the next group this workgroup requests
+    long long req_group = slice;                                  // global index of the next group this workgroup requests
     f32x4 ca[U], cb[U], na[U], nb[U], fa[U], fb[U];
     __amdgpu_buffer_rsrc_t ra, rb;
     auto open_group = [&]() __attribute__((always_inline)) {
@@ -300,10 +316,9 @@ void wgrad_big_kernel(const WgradArgs a) {
     auto loop = [&](auto PAR) __attribute__((always_inline)) {
         long long g = 0;
         do {
-            // Keep the four waves within three groups of each other: the two waves of a pair fetch the same rows, and in the batched
-            // launch (nine products streaming through each L2) a wave that has drifted finds its partner's rows evicted -- FETCH_SIZE
-            // 18.3 GB per fine-net batch without this barrier, 14.1 GB (every operand read once) with it; 0.17 % of the step.
+#ifdef MN_WG_SYNC                                            // A/B variant: a barrier per three groups
             __builtin_amdgcn_s_barrier();
+#endif
             step(PAR, ca, cb, fa, fb);
             step(PAR, na, nb, ca, cb);
             step(PAR, fa, fb, na, nb);
@@ -314,7 +329,7 @@ void wgrad_big_kernel(const WgradArgs a) {
     else if (wn == 0) loop(std::integral_constant<int, 0>{});
     else loop(std::integral_constant<int, 1>{});
     // D[i'][j]: i' = (r&3) + 8*(r>>2) + 4*kh is the A-side lane index, j = lane & 31 the B-side one
-    float* out = a.partial + ((size_t)b * a.slices + blockIdx.x) * (256 * 256);
+    float* out = a.partial + ((size_t)b * a.slices + slice) * (256 * 256);
 #pragma unroll
     for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
@@ -331,7 +346,7 @@ void wgrad_big_kernel(const WgradArgs a) {
             f32x4 sv;
 #pragma unroll
             for (int e = 0; e < 4; ++e) sv[e] = bsum[e] + __shfl_xor(bsum[e], 32, 64);      // even + odd points of every k-step
-            if (kh == 0) *(f32x4*)(a.bpartial + ((size_t)b * a.slices + blockIdx.x) * 256 + m0 + 4 * i) = sv;
+            if (kh == 0) *(f32x4*)(a.bpartial + ((size_t)b * a.slices + slice) * 256 + m0 + 4 * i) = sv;
         }
     }
 }
