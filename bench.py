@@ -7,9 +7,9 @@
 
 Metric (BASELINE.json): rays/sec on a 4096-ray batch with 64 coarse + 128 fine samples through the 8x256
 coarse/fine MLPs, fp32 -- BASELINE config #2, "lego coarse+fine 4096 rays, 64+128 samples, 8x256 MLP,
-1xMI355X fp32".  One step = one full render_rays pass (stratified sampling -> coarse MLP -> composite ->
-inverse-CDF resampling + merge -> fine MLP over all 192 depths -> composite) over one batch whose rays are
-resident in HBM.
+1xMI355X fp32".  One step = one full render_rays pass (jitter draw t_rand / u, nerf_process.py:58-60,162-163 ->
+stratified sampling -> coarse MLP -> composite -> inverse-CDF resampling + merge -> fine MLP over all 192
+depths -> composite) over one batch whose rays are resident in HBM.
 
 Scaling: the 4096-ray batch is SHARDED over the N GPUs -- 4096/N contiguous rays per rank
 (512 at N = 8), no data-path collective -- so `value` = 4096 * K / max-over-ranks time is STRONG scaled.
@@ -19,8 +19,13 @@ the same run for N > 1; at N = 1 the two are the same measurement.
 Also on the line: the 800x800 frame time (rows sharded over the ranks, ONE all-gather of the output tiles
 over RCCL), `roofline` for the dominant kernel (the fine-network fused MLP launch, hipEvent-timed on its
 launch stream), `bf16` (BASELINE config #5: the same step on the bf16 MFMA variant with its PSNR against the
-fp32 outputs of the same rays), `small_batch` (the same step at 256..2048 rays on one GPU: what a rank sees
-under strong scaling) and `cpu_baseline` (the CPU oracle timed on the host cores; rank 0, N = 1 only).
+fp32 outputs of the same rays, and its own `small_batch`), `small_batch` (the same step at 256..2048 rays on
+one GPU: what a rank sees under strong scaling) and `cpu_baseline` (the CPU oracle timed on the host cores;
+rank 0, N = 1 only).
+
+BENCH_SOLO_RANK=1 with RANK / WORLD_SIZE set rehearses ONE rank's share of an N-rank run alone (no process
+group; the frame leg renders this rank's rows only): the GPU pool admits at most 6 processes on a card, so an
+8-rank run cannot be rehearsed on a one-GPU box with 8 live ranks.
 
 Synthetic inputs: lego camera geometry, pose_spherical(0,-30,4), 4096 pixels from
 RandomState(0), Xavier(seed 0) weights with the density head x20, counter-based jitter seed 0.
@@ -50,6 +55,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3             # MI355X_MICROARCH.md: 256 CU x 256 FLO
 PEAK_BF16_MFMA_TFLOPS = 2500.0           # dense bf16 MFMA peak (the headline 5 PF figure includes 2:1 sparsity)
 LDS_DMA_CHIP_TBPS = 6.4                  # chip-wide L2 -> LDS fill rate, default cache policy (MI355X_MICROARCH.md, "ldsdma-fill")
 BF16_POINTS_PER_PASS = 256               # mlp_bf16.hip: a workgroup takes 4 waves x 64 points through one pass of the weight stream
+LAUNCHER_GRACE_S = float(os.environ.get("BENCH_LAUNCHER_GRACE_S", "10"))     # SIGTERM -> SIGKILL for the survivors of a failed run
 KERNEL_SOURCES = ("mlp_fp32.hip", "mlp_core.h", "layout.h", "common.h")
 
 
@@ -91,10 +97,12 @@ def launch_workers(n: int) -> int:
     for r in range(n):
         env = dict(os.environ)
         env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
-                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC (RCCL across processes); a value the user set wins
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env))
     rc = 0
     alive = set(range(n))
+    kill_at = None                                # deadline for the survivors of a failed run (SIGTERM sent, SIGKILL next)
     while alive:
         for r in sorted(alive):
             code = procs[r].poll()
@@ -106,6 +114,15 @@ def launch_workers(n: int) -> int:
                 sys.stderr.write(f"bench.py: worker rank {r} exited with status {code}; stopping the others\n")
                 for o in alive:
                     procs[o].terminate()          # exact children of this process, by PID
+                kill_at = time.monotonic() + LAUNCHER_GRACE_S
+        if alive and kill_at is not None and time.monotonic() >= kill_at:
+            # a rank blocked inside a collective or a driver call can sit out SIGTERM: do not wait for it forever
+            for o in sorted(alive):
+                sys.stderr.write(f"bench.py: worker rank {o} ignored SIGTERM for {LAUNCHER_GRACE_S:.0f} s; killing it\n")
+                procs[o].kill()
+            for o in sorted(alive):
+                procs[o].wait()
+            alive.clear()
         if alive:
             time.sleep(0.05)
     return rc
@@ -140,6 +157,7 @@ def worker(args) -> None:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    solo = os.environ.get("BENCH_SOLO_RANK") == "1"                     # this rank's share of a `world`-rank run, alone on the GPU
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
@@ -148,11 +166,11 @@ def worker(args) -> None:
     # one process per GPU; BENCH_BACKEND=gloo + fewer GPUs than ranks is only for rehearsing the multi-rank plumbing
     backend = os.environ.get("BENCH_BACKEND", "nccl")
     ndev = torch.cuda.device_count()
-    if world > ndev and backend == "nccl":
+    if world > ndev and backend == "nccl" and not solo:
         raise SystemExit(f"{world} ranks but {ndev} GPU(s): RCCL needs one GPU per rank (BENCH_BACKEND=gloo rehearses the plumbing)")
     dev = torch.device("cuda", local_rank % ndev)
     torch.cuda.set_device(dev)
-    use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"      # BENCH_FORCE_DIST: a 1-rank RCCL group on a one-GPU box
+    use_dist = (world > 1 and not solo) or os.environ.get("BENCH_FORCE_DIST") == "1"      # BENCH_FORCE_DIST: a 1-rank RCCL group on a one-GPU box
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(_free_port()))
@@ -198,13 +216,20 @@ def worker(args) -> None:
         o, d = ops.make_o_d_pixels(W, H, K, pose, pix)
         if fern:                                                            # NDC warp, near plane 1 (nerf_process.py:224-226)
             o, d = ops.ndc_rays(H, W, float(K[0][0]), 1.0, o, d)
-        b = SimpleNamespace(n=n, o=o, d=d, rays=torch.cat([o, d], -1).contiguous(),
+        b = SimpleNamespace(n=n, first=first, o=o, d=d, rays=torch.cat([o, d], -1).contiguous(),
                             t_rand=ops.fill_uniform(0, 0, first, n, SC, dev), u=ops.fill_uniform(0, 1, first, n, NF, dev),
                             out=(torch.empty(n, 3, device=dev), torch.empty(n, device=dev), torch.empty(n, 3, device=dev), torch.empty(n, device=dev)),
                             ws=torch.empty(ops.workspace_layout(cfg, n).total, dtype=torch.uint8, device=dev))
         return b
 
+    def draw_jitter(b):
+        """The step's own random draws (the reference: torch.rand inside pre_process / sample_pdf, nerf_process.py:58-60,162-163),
+        from the counter-based generator keyed on the global ray index; same seed every step, so the outputs are reproducible."""
+        ops.fill_uniform(0, 0, b.first, b.n, SC, dev, out=b.t_rand)
+        ops.fill_uniform(0, 1, b.first, b.n, NF, dev, out=b.u)
+
     def step(b):
+        draw_jitter(b)
         ops.render_rays(packed.net, blobs[0], blobs[1], cfg, b.rays, b.t_rand, b.u, workspace=b.ws, out=b.out)
 
     def timed_steps(b, warmup: int, steps: int) -> float:
@@ -276,8 +301,9 @@ def worker(args) -> None:
         blobs16 = packed.bf16()
         out16 = tuple(torch.empty_like(t) for t in main.out)
 
-        def step16():
-            ops.render_rays(packed.net, blobs16[0], blobs16[1], cfg16, main.rays, main.t_rand, main.u, workspace=main.ws, out=out16)
+        def step16(b=main, out=out16):
+            draw_jitter(b)
+            ops.render_rays(packed.net, blobs16[0], blobs16[1], cfg16, b.rays, b.t_rand, b.u, workspace=b.ws, out=out)
 
         step(main)                                           # fp32 outputs of this shard as the yardstick (same rays, same jitter)
         ref32 = tuple(t.clone() for t in main.out)
@@ -311,38 +337,60 @@ def worker(args) -> None:
         del raw16, zf16
 
     # ---- the same step at small batches (one GPU): what a rank runs under strong scaling ---------------------------
-    small = None
-    if world == 1 and not args.no_small_batch:
-        small = []
+    def small_batch_legs(step_fn, cfg_, blob_fine, is_bf16: bool, peak_tflops: float):
+        legs = []
         for n in (256, 512, 1024, 2048):
             b = make_batch(0, n)
             reps = max(args.steps, 20)
-            el = timed_steps(b, 3, reps)
-            zf = ops.workspace_views(cfg, n, b.ws)["z_f"].clone()
+            for _ in range(3):
+                step_fn(b)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                step_fn(b)
+            torch.cuda.synchronize(dev)
+            el = time.perf_counter() - t0
+            zf = ops.workspace_views(cfg_, n, b.ws)["z_f"].clone()
             rf = torch.empty(n, SC + NF, 4, device=dev)
-            ops.time_mlp_rays(packed.net, blobs[1], b.rays, zf, rf, 2, args.bf16)
-            kms = ops.time_mlp_rays(packed.net, blobs[1], b.rays, zf, rf, 20, args.bf16)
+            ops.time_mlp_rays(packed.net, blob_fine, b.rays, zf, rf, 2, is_bf16)
+            kms = ops.time_mlp_rays(packed.net, blob_fine, b.rays, zf, rf, 20, is_bf16)
             rps = n * reps / el
-            small.append({"rays": n, "ms_per_step": round(1e3 * el / reps, 4), "rays_per_s": round(rps, 1),
-                          "frac_of_roofline_end_to_end": round(rps * FLOP_PER_RAY / 1e12 / peak, 4),
-                          "fine_kernel_ms": round(kms, 4),
-                          "fine_kernel_frac": round(n * (SC + NF) * FLOP_PER_POINT / (kms * 1e-3) / 1e12 / peak, 4)})
+            legs.append({"rays": n, "ms_per_step": round(1e3 * el / reps, 4), "rays_per_s": round(rps, 1),
+                         "frac_of_roofline_end_to_end": round(rps * FLOP_PER_RAY / 1e12 / peak_tflops, 4),
+                         "fine_kernel_ms": round(kms, 4),
+                         "fine_kernel_frac": round(n * (SC + NF) * FLOP_PER_POINT / (kms * 1e-3) / 1e12 / peak_tflops, 4)})
             del b, zf, rf
+        return legs
+
+    small = None
+    if world == 1 and not args.no_small_batch:
+        small = small_batch_legs(step, cfg, blobs[1], args.bf16, peak)
+        if bf16_leg is not None:
+            legs16 = small_batch_legs(lambda b: step16(b, b.out), cfg16, blobs16[1], True, PEAK_BF16_MFMA_TFLOPS)
+            full16 = bf16_leg["rays_per_s"]
+            for leg in legs16:
+                leg["frac_of_4096_ray_rate"] = round(leg["rays_per_s"] / full16, 4)
+            bf16_leg["small_batch"] = legs16
 
     # ---- 800x800 frame, rows sharded over the ranks, one all-gather of the tiles ----------------------------
     frame_ms = None
+    def frame(fp):
+        if solo:                                                        # this rank's row block only; nothing to gather
+            return mdist.render_shard(H, W, K, fp, packed, opts, world, rank, seed=0, bf16=args.bf16), None
+        return mdist.render_frame(H, W, K, fp, packed, opts, seed=0, bf16=args.bf16)
+
     if args.frames > 0:
-        mdist.render_frame(H, W, K, pose, packed, opts, seed=0, bf16=args.bf16)            # warm-up frame
+        frame(pose)                                                     # warm-up frame
         torch.cuda.synchronize(dev)
         barrier()
         t0 = time.perf_counter()
         for f in range(args.frames):
             fpose = synthetic.fern_pose() if fern else synthetic.pose_spherical(3.0 * (f + 1), -30.0, 4.0)
-            rgb, disp = mdist.render_frame(H, W, K, fpose, packed, opts, seed=0, bf16=args.bf16)
+            rgb, disp = frame(fpose)
         torch.cuda.synchronize(dev)
         barrier()
         frame_ms = 1e3 * max_over_ranks(time.perf_counter() - t0) / args.frames
-        assert rgb.shape == (H, W, 3) and torch.isfinite(rgb).all()
+        assert (rgb.shape == (H, W, 3) or solo) and torch.isfinite(rgb).all()
 
     # ---- training step: forward + backward + Adam on this rank's 4096-ray batch --------------
     train = None
@@ -453,7 +501,7 @@ def worker(args) -> None:
                          f"{n_cpu} rays of the same 4096-ray batch, median of {len(reps)} reps; SURVEY section 6 timed the reference itself at "
                          "691 rays/s on 8 vCPU with its own 4096-ray chunks (larger GEMMs per call than this 1024-ray sample)"}
 
-    if rank == 0:
+    if rank == 0 or solo:
         head_value = value if headline_strong else value_weak
         head_ms = ms_strong if headline_strong else ms_weak
         per_gpu = n_s if headline_strong else N_RAYS
@@ -475,6 +523,9 @@ def worker(args) -> None:
             "frac_of_roofline_end_to_end": round(head_value / world * FLOP_PER_RAY / 1e12 / peak, 4),
             "roofline": roofline,
         }
+        if solo:
+            line["solo_rank"] = {"rank": rank, "of": world, "what": "BENCH_SOLO_RANK=1: this rank's share of the run timed alone (no process group, "
+                                 "no gather); `value` assumes every rank takes as long as this one"}
         if not args.bf16:
             line["frac_of_f32_mfma_roofline_end_to_end"] = line["frac_of_roofline_end_to_end"]
         if bf16_leg is not None:

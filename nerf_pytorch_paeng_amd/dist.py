@@ -10,7 +10,7 @@ so the assembled frame is bit-identical for any world size.  The reference is si
 """
 from __future__ import annotations
 
-from typing import Callable, Optional, Tuple
+from typing import Callable, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -60,6 +60,34 @@ def gather_tiles(local: torch.Tensor, H: int, W: int, group=None, force_collecti
     return torch.cat(parts, 0)
 
 
+def assemble_tiles(tiles: Sequence[torch.Tensor], H: int, W: int) -> torch.Tensor:
+    """``[H * W, C]`` frame from the per-rank tiles in rank order (what ``gather_tiles`` returns on every rank); checks that
+    tile r has exactly the rays of ``shard_rows(H, len(tiles), r)``."""
+    world = len(tiles)
+    for r, t in enumerate(tiles):
+        _, nr = shard_rows(H, world, r)
+        if t.shape[0] != nr * W:
+            raise ValueError(f"tile {r} of {world} has {t.shape[0]} rays, expected {nr * W}")
+    return tiles[0] if world == 1 else torch.cat(list(tiles), 0)
+
+
+def render_shard(H: int, W: int, K, pose, model, opts, world: int, rank: int, *, seed: int = 0, bf16: bool = False) -> torch.Tensor:
+    """Rank ``rank``'s ``[rows_local * W, 4]`` tile (rgb + disp) of an H x W frame split over ``world`` ranks: rays generated on
+    this device from (K, pose, row range), jitter keyed on the GLOBAL ray index (``ray_offset`` = first pixel of the block), the
+    fine outputs when ``N_samples_f > 0`` else the coarse ones (test.py:42-47).  No communication."""
+    from . import nerf_process as NP
+    from . import ops
+    from .weights import packed_for
+    packed = packed_for(model)
+    r0, nr = shard_rows(H, world, rank)
+    _, d = ops.make_o_d(W, H, K, pose, packed.device, row0=r0, n_rows=nr, want_origins=False)
+    p = pose if isinstance(pose, torch.Tensor) else torch.as_tensor(pose)
+    o = p[:3, -1].to(packed.device, torch.float32).expand(d.shape)
+    rc, dc, rf, df = NP.batchify_rays_and_render_by_chunk(o, d, packed, None, H, W, K, opts, seed=seed, ray_offset=r0 * W, bf16=bf16)
+    rgb, disp = (rc, dc) if int(opts.N_samples_f) == 0 else (rf, df)
+    return torch.cat([rgb, disp[:, None]], -1)
+
+
 def render_frame(H: int, W: int, K, pose, model, opts, *, seed: int = 0, group=None, bf16: bool = False,
                  render_rows_fn: Optional[Callable[[int, int], torch.Tensor]] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """Render one H x W frame sharded over the process group; returns (rgb [H,W,3], disp [H,W]) on every rank.
@@ -72,21 +100,9 @@ def render_frame(H: int, W: int, K, pose, model, opts, *, seed: int = 0, group=N
         world, rank = dist.get_world_size(group), dist.get_rank(group)
     else:
         world, rank = 1, 0
-    row0, n_rows = shard_rows(H, world, rank)
     if render_rows_fn is None:
-        from . import nerf_process as NP
-        from . import ops
-        from .weights import packed_for
-        packed = packed_for(model)
-
-        def render_rows_fn(r0: int, nr: int) -> torch.Tensor:
-            _, d = ops.make_o_d(W, H, K, pose, packed.device, row0=r0, n_rows=nr, want_origins=False)
-            p = pose if isinstance(pose, torch.Tensor) else torch.as_tensor(pose)
-            o = p[:3, -1].to(packed.device, torch.float32).expand(d.shape)
-            rc, dc, rf, df = NP.batchify_rays_and_render_by_chunk(o, d, packed, None, H, W, K, opts, seed=seed,
-                                                                  ray_offset=r0 * W, bf16=bf16)
-            rgb, disp = (rc, dc) if int(opts.N_samples_f) == 0 else (rf, df)      # test.py:42-47
-            return torch.cat([rgb, disp[:, None]], -1)
-    local = render_rows_fn(row0, n_rows)
+        local = render_shard(H, W, K, pose, model, opts, world, rank, seed=seed, bf16=bf16)
+    else:
+        local = render_rows_fn(*shard_rows(H, world, rank))
     full = gather_tiles(local, H, W, group)
     return full[:, :3].reshape(H, W, 3), full[:, 3].reshape(H, W)

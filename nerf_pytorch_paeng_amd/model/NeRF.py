@@ -32,6 +32,12 @@ class NeRFModule(nn.Module):
         self.linear_density = nn.Linear(W, 1)
         self.linear_color = nn.Linear(W // 2, 3)
 
+    def __getstate__(self):
+        # the back reference to the parent NeRF is a weakref: not state (pickle / deepcopy / torch.save); NeRF re-binds it
+        state = self.__dict__.copy()
+        state.pop("_parent", None)
+        return state
+
     def forward(self, x):
         """x [n, input_ch + input_ch_d] -> [n, 4], like the reference's sub-module (model/NeRF.py:33-52; its NeRF.forward merely
         dispatches to ``model_coarse`` / ``model_fine``, NeRF.py:75-78).  Routed through the parent NeRF, which owns the packed
@@ -48,12 +54,20 @@ class NeRF(nn.Module):
         super().__init__()
         self.model_coarse = NeRFModule(D, W, input_ch, input_ch_d, skips)
         self.model_fine = NeRFModule(D, W, input_ch, input_ch_d, skips)
-        # weak back references (not sub-modules, not state): model.model_coarse(x) works like the reference's
-        import weakref
-        object.__setattr__(self.model_coarse, "_parent", weakref.ref(self))
-        object.__setattr__(self.model_fine, "_parent", weakref.ref(self))
+        self._bind_children()
         self.apply(self._init_weights)                                   # NeRF.py:60,63-65
         self.gt_intrinsic, self.gt_extrinsic = gt_camera_param if gt_camera_param is not None else (None, None)
+
+    def _bind_children(self) -> None:
+        """Weak back references (not sub-modules, not state): ``model.model_coarse(x)`` works like the reference's.  Re-made after
+        unpickling / ``copy.deepcopy`` (``__setstate__``), so a copy's sub-modules route through the COPY."""
+        import weakref
+        for child in (self.model_coarse, self.model_fine):
+            object.__setattr__(child, "_parent", weakref.ref(self))
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._bind_children()
 
     def _init_weights(self, m):
         if isinstance(m, nn.Linear):

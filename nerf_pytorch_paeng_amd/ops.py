@@ -130,9 +130,14 @@ def ndc_rays(H: int, W: int, focal: float, near: float, rays_o: torch.Tensor, ra
 # ------------------------------------------------------------------------------------------------
 # sampling
 # ------------------------------------------------------------------------------------------------
-def fill_uniform(seed: int, stream_id: int, ray0: int, n_rays: int, n_samples: int, device) -> torch.Tensor:
+def fill_uniform(seed: int, stream_id: int, ray0: int, n_rays: int, n_samples: int, device, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     device = torch.device(device)
-    out = torch.empty(n_rays, n_samples, dtype=torch.float32, device=device)
+    if out is None:
+        out = torch.empty(n_rays, n_samples, dtype=torch.float32, device=device)
+    else:
+        if tuple(out.shape) != (n_rays, n_samples):
+            raise MiNerfError(f"out must be [{n_rays}, {n_samples}], got {tuple(out.shape)}")
+        device = out.device
     with _guard(device):
         check(lib().mi_nerf_fill_uniform(seed & 0xFFFFFFFF, stream_id, ray0, n_rays, n_samples, dev_ptr(out), stream_ptr(device)),
               "mi_nerf_fill_uniform")

@@ -196,6 +196,15 @@ def render_train(rays: torch.Tensor, model: torch.nn.Module, opts, *, t_rand=Non
     return out
 
 
+def rank_seed(seed: int, rank: int) -> int:
+    """Per-rank jitter seed: ``seed`` mixed with a hash of the rank (distinct for every rank below 2^32, rank 0 included)."""
+    h = ((rank + 1) * 0x9E3779B1) & 0xFFFFFFFF
+    h ^= h >> 15
+    h = (h * 0x85EBCA77) & 0xFFFFFFFF
+    h ^= h >> 13
+    return (seed ^ h) & 0xFFFFFFFF
+
+
 class RenderModule(torch.nn.Module):
     """``forward(rays_o, rays_d, H, W, K)`` = ``batchify_rays_and_render_by_chunk`` on the wrapped model.
 
@@ -206,9 +215,10 @@ class RenderModule(torch.nn.Module):
     come out of ONE autograd node, so they become ready together at the end of the backward: the all-reduce of the 4.8 MB of
     gradients (~0.1 ms on xGMI) follows the 20 ms backward, it does not overlap with it.
 
-    Jitter: without explicit ``t_rand`` / ``u`` / ``ray_offset`` the generator is keyed on (seed, ray_offset + local ray index);
-    every rank would then draw the SAME jitter for its local ray i.  ``forward`` therefore offsets the key by
-    ``rank * 2^24`` rays unless the caller passes ``ray_offset``."""
+    Jitter: without explicit ``t_rand`` / ``u`` / ``ray_offset`` / ``seed`` the generator is keyed on (seed, local ray index);
+    every rank would then draw the SAME jitter for its local ray i.  ``forward`` therefore folds the rank into the SEED
+    (not into the 32-bit ray counter, which would wrap for large rank x batch products) whenever one of the two random
+    tensors is generated internally and the caller pins neither ``ray_offset`` nor ``seed``."""
 
     def __init__(self, model: torch.nn.Module, posenc, opts):
         super().__init__()
@@ -216,8 +226,9 @@ class RenderModule(torch.nn.Module):
 
     def forward(self, rays_o, rays_d, H, W, K, **kw):
         from . import nerf_process as NP
-        if "ray_offset" not in kw and "t_rand" not in kw:
+        generates = kw.get("t_rand") is None or (kw.get("u") is None and int(self.opts.N_samples_f) > 0)
+        if generates and "ray_offset" not in kw and "seed" not in kw:
             import torch.distributed as dist
             if dist.is_available() and dist.is_initialized():
-                kw["ray_offset"] = dist.get_rank() << 24
+                kw["seed"] = rank_seed(NP._next_seed(None), dist.get_rank())
         return NP.batchify_rays_and_render_by_chunk(rays_o, rays_d, self.model, self.posenc, H, W, K, self.opts, **kw)

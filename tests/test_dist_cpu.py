@@ -81,3 +81,50 @@ def test_sharded_frame_equals_single_process(tmp_path, H, W):
         assert rgb.shape == (H, W, 3) and disp.shape == (H, W)
         np.testing.assert_array_equal(rgb.reshape(-1, 3), ref[:, :3])      # bit-identical assembly on every rank
         np.testing.assert_array_equal(disp.reshape(-1), ref[:, 3])
+
+
+def _tile_of_rows(r0, nr, W):
+    """A stand-in renderer for plumbing tests: channel c of global ray g is a fixed function of (g, c)."""
+    g = torch.arange(r0 * W, (r0 + nr) * W, dtype=torch.float32)
+    return torch.stack([g * 0.25 + c for c in range(4)], -1)
+
+
+def _worker8(rank, world, port, H, W, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from nerf_pytorch_paeng_amd.dist import render_frame, shard_rows
+        seen = []
+
+        def rows(r0, nr):
+            seen.append((r0, nr))
+            return _tile_of_rows(r0, nr, W)
+
+        rgb, disp = render_frame(H, W, None, None, None, None, render_rows_fn=rows)
+        assert seen == [shard_rows(H, world, rank)]
+        np.save(os.path.join(out_dir, f"frame_{rank}.npy"), torch.cat([rgb.reshape(-1, 3), disp.reshape(-1, 1)], -1).numpy())
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("H,W", [(800, 3), (378, 5)])       # config #3's 8 x 100 rows; fern's ragged 48, 48, 47 x 6 rows
+def test_eight_rank_gather_assembles_the_frame(tmp_path, H, W):
+    """The shard / pad / all_gather_into_tensor / un-pad path of dist.render_frame at the world size the driver's 8-GPU run uses
+    (gloo, 8 CPU processes; the per-rank renderer is a stand-in): every rank ends with the whole frame, rows in order."""
+    world = 8
+    mp.spawn(_worker8, args=(world, _free_port(), H, W, str(tmp_path)), nprocs=world, join=True)
+    ref = _tile_of_rows(0, H, W).numpy()
+    for r in range(world):
+        np.testing.assert_array_equal(np.load(tmp_path / f"frame_{r}.npy"), ref)
+
+
+def test_assemble_tiles_checks_the_split():
+    from nerf_pytorch_paeng_amd.dist import assemble_tiles, shard_rows
+    H, W = 378, 4
+    tiles = [_tile_of_rows(*shard_rows(H, 8, r), W) for r in range(8)]
+    assert torch.equal(assemble_tiles(tiles, H, W), _tile_of_rows(0, H, W))
+    with pytest.raises(ValueError):
+        assemble_tiles(tiles[:7] + [tiles[7][:-1]], H, W)

@@ -591,6 +591,33 @@ def test_bf16_mlp_vs_bf16_oracle(packed_big, lego_rays):
         assert float(e.max()) < 0.2, float(e.max())      # a flipped bf16 rounding of one activation, amplified by the x20 density head
 
 
+@pytest.mark.parametrize("D,skip", [(7, 5), (3, -1), (8, 3), (2, -1), (6, 4), (9, 0)])
+def test_bf16_other_depths_and_skip_positions(D, skip, lego_rays):
+    """The bf16 kernel addresses its B fragments by explicit AGPR number, with two statically unrolled polarities (which fragment
+    set a layer reads) and a separate instantiation for the skip layer at odd / even l -- a polarity error would give silently
+    wrong colours.  check_net_bf16 accepts D = 2..16 and any skip position (config.py:54-57 --netDepth; NeRF.py:25 skips), so each
+    code path runs here against the bf16 oracle: odd D (tail reads set 0), even D (set 1), the skip layer at even l
+    (skip = 3, 5: layer_10<SKIP>) and at odd l (skip = 0, 4: layer_01<SKIP>), no skip at all."""
+    skips = (skip,) if skip >= 0 else ()
+    sd = synthetic.make_state_dict(31 + D, D, 256, skips=skips)
+    packed = weights.PackedNeRF.from_state_dict(sd, DEV)
+    assert packed.net.D == D and packed.net.skip == skip
+    n, S = 37, 96
+    rays = lego_rays[:n].contiguous()
+    z = torch.sort(T(R.counter_uniform(4, 0, 0, n, S)) * 4 + 2, -1)[0]
+    raw16 = ops.mlp_rays(packed.net, packed.bf16()[1], rays, z.to(DEV), bf16=True).cpu()
+    ref = R.mlp_forward_bf16(sd, "model_fine.", R.embed(rays.cpu(), z, 10, 4), D, 63, 27, skips=skips).reshape(n, S, 4)
+    e = (raw16 - ref).abs()
+    rel = [float(e[..., c].mean() / ref[..., c].abs().mean()) for c in range(4)]
+    print(f"bf16 kernel vs bf16 oracle D={D} skip={skip}: mean |err| / mean |ref| per channel {[f'{v:.1e}' for v in rel]}, max |err| {float(e.max()):.3e}")
+    assert torch.isfinite(raw16).all()
+    assert max(rel) < 2e-3 and float(e.max()) < 0.2, (rel, float(e.max()))
+    # and the fp32 kernel on the same network (its depth / skip position are run-time values)
+    raw32 = ops.mlp_rays(packed.net, packed.fine, rays, z.to(DEV)).cpu()
+    ref32 = R.mlp_forward(sd, "model_fine.", R.embed(rays.cpu(), z, 10, 4).double(), D, 63, 27, skips=skips, dtype=torch.float64).reshape(n, S, 4)
+    assert err(raw32, ref32) <= 2e-4, err(raw32, ref32)
+
+
 def test_config2_all_rays_vs_oracle(packed_big, lego_rays):
     """BASELINE config #2 at full size, EVERY ray against the CPU oracle: coarse colours and disparities directly; fine outputs
     with the depths pinned to the ones the HIP path sampled (sample_pdf's branch flips are counted separately below)."""
