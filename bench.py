@@ -7,9 +7,10 @@
 
 Metric (BASELINE.json): rays/sec on a 4096-ray batch with 64 coarse + 128 fine samples through the 8x256
 coarse/fine MLPs, fp32 -- BASELINE config #2, "lego coarse+fine 4096 rays, 64+128 samples, 8x256 MLP,
-1xMI355X fp32".  One step = one full render_rays pass (jitter draw t_rand / u, nerf_process.py:58-60,162-163 ->
-stratified sampling -> coarse MLP -> composite -> inverse-CDF resampling + merge -> fine MLP over all 192
-depths -> composite) over one batch whose rays are resident in HBM.
+1xMI355X fp32".  One step = one full render_rays pass (stratified sampling with its jitter draw, nerf_process.py:58-60 -> coarse
+MLP -> composite -> inverse-CDF resampling with its jitter draw, :162-163, + merge -> fine MLP over all 192
+depths -> composite) over one batch whose rays are resident in HBM; the jitter is drawn INSIDE the step, by the
+sampling kernels themselves (counter-based generator keyed on the global ray index).
 
 Scaling: the 4096-ray batch is SHARDED over the N GPUs -- 4096/N contiguous rays per rank
 (512 at N = 8), no data-path collective -- so `value` = 4096 * K / max-over-ranks time is STRONG scaled.
@@ -217,20 +218,16 @@ def worker(args) -> None:
         if fern:                                                            # NDC warp, near plane 1 (nerf_process.py:224-226)
             o, d = ops.ndc_rays(H, W, float(K[0][0]), 1.0, o, d)
         b = SimpleNamespace(n=n, first=first, o=o, d=d, rays=torch.cat([o, d], -1).contiguous(),
-                            t_rand=ops.fill_uniform(0, 0, first, n, SC, dev), u=ops.fill_uniform(0, 1, first, n, NF, dev),
+                            cfg=ops.render_cfg(opts.near, opts.far, SC, NF, False, args.bf16, seed=0, ray_offset=first),
+                            cfg16=ops.render_cfg(opts.near, opts.far, SC, NF, False, True, seed=0, ray_offset=first),
                             out=(torch.empty(n, 3, device=dev), torch.empty(n, device=dev), torch.empty(n, 3, device=dev), torch.empty(n, device=dev)),
                             ws=torch.empty(ops.workspace_layout(cfg, n).total, dtype=torch.uint8, device=dev))
         return b
 
-    def draw_jitter(b):
-        """The step's own random draws (the reference: torch.rand inside pre_process / sample_pdf, nerf_process.py:58-60,162-163),
-        from the counter-based generator keyed on the global ray index; same seed every step, so the outputs are reproducible."""
-        ops.fill_uniform(0, 0, b.first, b.n, SC, dev, out=b.t_rand)
-        ops.fill_uniform(0, 1, b.first, b.n, NF, dev, out=b.u)
-
     def step(b):
-        draw_jitter(b)
-        ops.render_rays(packed.net, blobs[0], blobs[1], cfg, b.rays, b.t_rand, b.u, workspace=b.ws, out=b.out)
+        # t_rand = u = None: the step draws its own jitter (the reference: torch.rand inside pre_process / sample_pdf) in the sampling
+        # kernels, keyed on (seed 0, global ray index b.first + ray, sample): same values every step, so the outputs are reproducible
+        ops.render_rays(packed.net, blobs[0], blobs[1], b.cfg, b.rays, None, None, workspace=b.ws, out=b.out)
 
     def timed_steps(b, warmup: int, steps: int) -> float:
         """W untimed + EXACTLY K timed steps, barrier + synchronize on both sides, max over ranks (seconds)."""
@@ -302,8 +299,7 @@ def worker(args) -> None:
         out16 = tuple(torch.empty_like(t) for t in main.out)
 
         def step16(b=main, out=out16):
-            draw_jitter(b)
-            ops.render_rays(packed.net, blobs16[0], blobs16[1], cfg16, b.rays, b.t_rand, b.u, workspace=b.ws, out=out)
+            ops.render_rays(packed.net, blobs16[0], blobs16[1], b.cfg16, b.rays, None, None, workspace=b.ws, out=out)
 
         step(main)                                           # fp32 outputs of this shard as the yardstick (same rays, same jitter)
         ref32 = tuple(t.clone() for t in main.out)
@@ -475,7 +471,9 @@ def worker(args) -> None:
         # the GPU box gives one GPU's job a 16-core share of a many-core host: do not oversubscribe
         n_thr = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
         torch.set_num_threads(n_thr)
-        rc, tc, uc = main.rays.cpu(), main.t_rand.cpu(), main.u.cpu()
+        # the same jitter the GPU step draws in its kernels: (seed 0, global ray index, sample)
+        rc = main.rays.cpu()
+        tc, uc = ops.fill_uniform(0, 0, main.first, main.n, SC, dev).cpu(), ops.fill_uniform(0, 1, main.first, main.n, NF, dev).cpu()
         pcfg = R.PathConfig()
         with torch.no_grad():
             R.render_rays(rc[:256], sd, pcfg, tc[:256], uc[:256])                            # warm-up

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define MI_NERF_ABI_VERSION 1
+#define MI_NERF_ABI_VERSION 2   /* 2: mi_nerf_render_cfg grew seed / reserved / ray_offset (in-kernel jitter) */
 
 /* status codes */
 #define MI_NERF_OK 0
@@ -132,6 +132,11 @@ int mi_nerf_mlp_rays(const mi_nerf_net* net, const void* packed_dev, const float
 /* bf16-MFMA variant of the fused entry (packed blob from mi_nerf_pack_weights_bf16). */
 int mi_nerf_mlp_rays_bf16(const mi_nerf_net* net, const void* packed_bf16_dev, const float* rays_dev,
                           const float* z_dev, int64_t n_rays, int S, float* raw_dev, void* stream);
+/* The same with the launch shape pinned: points_per_wave 64 (standard: 256 points per workgroup and pass of the weight
+ * stream), 32 (small-launch shape: 128) or 0 (chosen per launch, as mi_nerf_mlp_rays_bf16 does: the 32-point shape only
+ * where the 64-point one would leave SIMDs idle, e.g. a 512-ray shard).  Results are identical bit for bit. */
+int mi_nerf_mlp_rays_bf16_shape(const mi_nerf_net* net, const void* packed_bf16_dev, const float* rays_dev,
+                                const float* z_dev, int64_t n_rays, int S, float* raw_dev, int points_per_wave, void* stream);
 
 /* a10 post_process(outputs, z_vals, rays_d)                              nerf_process.py:89-140
  * raw [n,S,4], z [n,S], rays [n, ray_stride] with the direction at floats 3..5 when ray_stride == 6, or a
@@ -142,14 +147,22 @@ int mi_nerf_composite(const float* raw_dev, const float* z_dev, const float* ray
 
 /* a5  render_rays(rays, model, posenc, opts)                            nerf_process.py:185-216
  * Whole coarse(+fine) pipeline for n rays on one stream, no host synchronisation.
- * t_rand [n,Sc] and u [n,Nf] are always explicit (fill them with mi_nerf_fill_uniform or inject).
+ * Randomness (the reference draws unseeded torch.rand inside pre_process / sample_pdf, nerf_process.py:58-60,162-163): pass
+ * t_rand [n,Sc] / u [n,Nf] to inject explicit uniforms, or NULL to have the consuming kernels draw them from the counter-based
+ * generator keyed on (cfg->seed, cfg->ray_offset + ray index, sample index) -- exactly the values mi_nerf_fill_uniform(seed,
+ * stream 0 / 1, ray_offset, ...) writes, without the tensors.  u is ignored when det != 0.
+ * Launches: stratified depths | coarse net | composite + resample + merge | fine net | composite.
  * Workspace (caller-allocated, mi_nerf_render_workspace_bytes): z_c, raw_c, weights_c, z_f, raw_f.
  * Outputs: rgb_c [n,3], disp_c [n]; rgb_f [n,3], disp_f [n] when Nf > 0 (else may be NULL). */
 typedef struct mi_nerf_render_cfg {
     float near_, far_;     /* opts.near / opts.far   (nerf_process.py:44,47) */
     int32_t Sc, Nf;        /* opts.N_samples_c / _f  (config.py:72-73)       */
     int32_t det;           /* opts.perturb == 0.     (nerf_process.py:65)    */
-    int32_t use_bf16;      /* 0: fp32 MFMA (default); 1: bf16 MFMA variant   */
+    int32_t use_bf16;      /* 0: fp32 MFMA (default); 1: bf16 MFMA variant, launch shape chosen per launch;
+                              2 / 3: bf16 with 64 / 32 points per wave pinned (A/B measurements) */
+    uint32_t seed;         /* in-kernel jitter (t_rand / u NULL): generator seed ...             */
+    uint32_t reserved;     /* must be 0                                                          */
+    int64_t ray_offset;    /* ... and the GLOBAL index of ray 0 (chunk / shard invariant frames) */
 } mi_nerf_render_cfg;
 size_t mi_nerf_render_workspace_bytes(const mi_nerf_render_cfg* cfg, int64_t n_rays);
 int mi_nerf_render_rays(const mi_nerf_net* net, const void* packed_coarse_dev, const void* packed_fine_dev,

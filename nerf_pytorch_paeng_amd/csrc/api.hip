@@ -51,7 +51,9 @@ int pack_map_bf16(const mi_nerf_net*, int32_t*, size_t);
 int pack_apply_bf16(const mi_nerf_net*, const int32_t*, const float*, void*, size_t, hipStream_t);
 int mlp_rays_fp32(const mi_nerf_net*, const void*, const float*, const float*, int64_t, int, float*, hipStream_t);
 int mlp_embedded_fp32(const mi_nerf_net*, const void*, const float*, int64_t, float*, hipStream_t);
-int mlp_rays_bf16(const mi_nerf_net*, const void*, const float*, const float*, int64_t, int, float*, hipStream_t);
+int mlp_rays_bf16(const mi_nerf_net*, const void*, const float*, const float*, int64_t, int, float*, hipStream_t, int points_per_wave);
+// use_bf16 of mi_nerf_render_cfg / mi_nerf_time_mlp_rays -> launch shape of the bf16 kernel (0: chosen per launch)
+static inline int bf16_points_per_wave(int use_bf16) { return use_bf16 == 2 ? 64 : (use_bf16 == 3 ? 32 : (use_bf16 == 4 ? 832 : 0)); }
 int mlp_rays_fp32_stash(const mi_nerf_net*, const void*, const float*, const float*, int64_t, int, float*, float*, float*, float*, unsigned*,
                         unsigned*, hipStream_t);
 int mlp_backward_fp32(const mi_nerf_net*, const void*, const void*, const float*, const float*, int64_t, int, const float*, const void*, void*,
@@ -74,13 +76,15 @@ int stage_make_o_d(int, int, const float*, const float*, int, int, float*, float
 int stage_make_o_d_pixels(int, int, const float*, const float*, const int64_t*, int64_t, float*, float*, hipStream_t);
 int stage_ndc(int, int, float, float, const float*, int64_t, const float*, int64_t, int64_t, float*, float*, hipStream_t);
 int stage_fill_uniform(uint32_t, uint32_t, int64_t, int64_t, int, float*, hipStream_t);
-int stage_stratified(int64_t, int, float, float, const float*, float*, hipStream_t);
+int stage_stratified(int64_t, int, float, float, const float*, uint32_t, int64_t, float*, hipStream_t);
 int stage_embed(const float*, const float*, int64_t, int, int, int, float*, hipStream_t);
 int stage_posenc(const float*, int64_t, int, float*, hipStream_t);
 int stage_composite(const float*, const float*, const float*, int, int64_t, int, float*, float*, float*, float*, float*, hipStream_t);
 int stage_composite_backward(const float*, const float*, const float*, int, int64_t, int, const float*, float*, hipStream_t);
 int stage_sample_pdf(const float*, const float*, int64_t, int, int, int, const float*, float*, hipStream_t);
-int stage_fine_z(const float*, const float*, int64_t, int, int, int, const float*, float*, float*, hipStream_t);
+int stage_fine_z(const float*, const float*, int64_t, int, int, int, const float*, uint32_t, int64_t, float*, float*, hipStream_t);
+int stage_composite_fine_z(const float*, const float*, const float*, int64_t, int, int, int, const float*, uint32_t, int64_t, float*, float*, float*,
+                           float*, hipStream_t);
 
 static int check_net_basic(const mi_nerf_net* net) {
     MN_CHECK_ARG(net != nullptr, "net is NULL");
@@ -179,14 +183,16 @@ int mi_nerf_fill_uniform(uint32_t seed, uint32_t stream_id, int64_t ray0, int64_
     return stage_fill_uniform(seed, stream_id, ray0, n_rays, S, out, (hipStream_t)st);
 }
 int mi_nerf_stratified_z(int64_t n_rays, int S, float near_, float far_, const float* t_rand, float* z, void* st) {
-    return stage_stratified(n_rays, S, near_, far_, t_rand, z, (hipStream_t)st);
+    MN_CHECK_ARG(t_rand != nullptr || n_rays == 0, "t_rand is NULL");
+    return stage_stratified(n_rays, S, near_, far_, t_rand, 0, 0, z, (hipStream_t)st);
 }
 int mi_nerf_sample_pdf(const float* bins, const float* weights, int64_t n, int B, int N, int det, const float* u, float* out, void* st) {
     return stage_sample_pdf(bins, weights, n, B, N, det, u, out, (hipStream_t)st);
 }
 int mi_nerf_fine_z(const float* z_c, const float* w_c, int64_t n, int Sc, int Nf, int det, const float* u, float* z_f, float* z_s,
                    void* st) {
-    return stage_fine_z(z_c, w_c, n, Sc, Nf, det, u, z_f, z_s, (hipStream_t)st);
+    MN_CHECK_ARG(det || u != nullptr || n == 0, "u is NULL (and det == 0)");
+    return stage_fine_z(z_c, w_c, n, Sc, Nf, det, u, 0, 0, z_f, z_s, (hipStream_t)st);
 }
 int mi_nerf_embed(const float* rays, const float* z, int64_t n_rays, int S, int L_x, int L_d, float* out, void* st) {
     return stage_embed(rays, z, n_rays, S, L_x, L_d, out, (hipStream_t)st);
@@ -201,7 +207,11 @@ int mi_nerf_mlp_rays(const mi_nerf_net* net, const void* packed, const float* ra
 }
 int mi_nerf_mlp_rays_bf16(const mi_nerf_net* net, const void* packed, const float* rays, const float* z, int64_t n_rays, int S,
                           float* raw, void* st) {
-    return mlp_rays_bf16(net, packed, rays, z, n_rays, S, raw, (hipStream_t)st);
+    return mlp_rays_bf16(net, packed, rays, z, n_rays, S, raw, (hipStream_t)st, 0);
+}
+int mi_nerf_mlp_rays_bf16_shape(const mi_nerf_net* net, const void* packed, const float* rays, const float* z, int64_t n_rays, int S,
+                                float* raw, int points_per_wave, void* st) {
+    return mlp_rays_bf16(net, packed, rays, z, n_rays, S, raw, (hipStream_t)st, points_per_wave);
 }
 int mi_nerf_composite(const float* raw, const float* z, const float* rays, int ray_stride, int64_t n, int S, float* rgb, float* disp,
                       float* acc, float* weights, float* depth, void* st) {
@@ -322,24 +332,29 @@ int mi_nerf_render_rays(const mi_nerf_net* net, const void* packed_c, const void
     if (int rc = workspace_layout(cfg, n, &L)) return rc;
     if (n == 0) return MI_NERF_OK;
     MN_CHECK_ARG(ws_bytes >= L.total, "workspace too small: %zu < %zu", ws_bytes, L.total);
-    MN_CHECK_ARG(rays && t_rand && rgb_c && disp_c && packed_c && (ws || L.total == 0), "NULL pointer");
-    MN_CHECK_ARG(cfg->Nf == 0 || (packed_f && rgb_f && disp_f && (cfg->det || u)), "fine pass needs packed_fine, outputs and u");
+    MN_CHECK_ARG(rays && rgb_c && disp_c && packed_c && (ws || L.total == 0), "NULL pointer");
+    MN_CHECK_ARG(cfg->Nf == 0 || (packed_f && rgb_f && disp_f), "fine pass needs packed_fine and outputs");
+    MN_CHECK_ARG(cfg->reserved == 0, "mi_nerf_render_cfg.reserved must be 0");
     char* w = (char*)ws;
     float* z_c = (float*)(w + L.z_c);
     float* raw_c = (float*)(w + L.raw_c);
     float* wts_c = (float*)(w + L.weights_c);
     const int Sc = cfg->Sc, St = cfg->Sc + cfg->Nf;
     // 1-a) stratified depths; 2-a) coarse net; 3-a) composite          (nerf_process.py:187-198)
-    if (int rc = stage_stratified(n, Sc, cfg->near_, cfg->far_, t_rand, z_c, st)) return rc;
-    if (int rc = cfg->use_bf16 ? mlp_rays_bf16(net, packed_c, rays, z_c, n, Sc, raw_c, st)
+    // t_rand / u NULL: the jitter is drawn inside the consuming kernels (cfg->seed, cfg->ray_offset + ray, sample)
+    if (int rc = stage_stratified(n, Sc, cfg->near_, cfg->far_, t_rand, cfg->seed, cfg->ray_offset, z_c, st)) return rc;
+    MN_CHECK_ARG(cfg->use_bf16 >= 0 && cfg->use_bf16 <= 4, "use_bf16 must be 0..4 (got %d)", cfg->use_bf16);
+    const int ppw = bf16_points_per_wave(cfg->use_bf16);
+    if (int rc = cfg->use_bf16 ? mlp_rays_bf16(net, packed_c, rays, z_c, n, Sc, raw_c, st, ppw)
                                : mlp_rays_fp32(net, packed_c, rays, z_c, n, Sc, raw_c, st)) return rc;
-    if (int rc = stage_composite(raw_c, z_c, rays, 6, n, Sc, rgb_c, disp_c, nullptr, wts_c, nullptr, st)) return rc;
-    if (cfg->Nf > 0) {
-        // 1-b) resample + merge; 2-b) fine net over all Sc+Nf depths; 3-b) composite   (:200-213)
+    if (cfg->Nf == 0) return stage_composite(raw_c, z_c, rays, 6, n, Sc, rgb_c, disp_c, nullptr, wts_c, nullptr, st);
+    {
+        // 3-a) + 1-b) composite, resample + merge in one launch; 2-b) fine net over all Sc+Nf depths; 3-b) composite   (:198-213)
         float* z_f = (float*)(w + L.z_f);
         float* raw_f = (float*)(w + L.raw_f);
-        if (int rc = stage_fine_z(z_c, wts_c, n, Sc, cfg->Nf, cfg->det, u, z_f, nullptr, st)) return rc;
-        if (int rc = cfg->use_bf16 ? mlp_rays_bf16(net, packed_f, rays, z_f, n, St, raw_f, st)
+        if (int rc = stage_composite_fine_z(raw_c, z_c, rays, n, Sc, cfg->Nf, cfg->det, u, cfg->seed, cfg->ray_offset, rgb_c, disp_c, wts_c, z_f, st))
+            return rc;
+        if (int rc = cfg->use_bf16 ? mlp_rays_bf16(net, packed_f, rays, z_f, n, St, raw_f, st, ppw)
                                    : mlp_rays_fp32(net, packed_f, rays, z_f, n, St, raw_f, st)) return rc;
         if (int rc = stage_composite(raw_f, z_f, rays, 6, n, St, rgb_f, disp_f, nullptr, nullptr, nullptr, st)) return rc;
     }
@@ -356,7 +371,7 @@ int mi_nerf_time_mlp_rays(const mi_nerf_net* net, const void* packed, const floa
     int rc = MI_NERF_OK;
     MN_HIP(hipEventRecord(e0, st));
     for (int i = 0; i < iters && rc == MI_NERF_OK; ++i)
-        rc = use_bf16 ? mlp_rays_bf16(net, packed, rays, z, n_rays, S, raw, st) : mlp_rays_fp32(net, packed, rays, z, n_rays, S, raw, st);
+        rc = use_bf16 ? mlp_rays_bf16(net, packed, rays, z, n_rays, S, raw, st, bf16_points_per_wave(use_bf16)) : mlp_rays_fp32(net, packed, rays, z, n_rays, S, raw, st);
     MN_HIP(hipEventRecord(e1, st));
     MN_HIP(hipEventSynchronize(e1));
     float ms = 0.f;

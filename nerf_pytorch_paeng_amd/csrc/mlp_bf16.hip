@@ -15,7 +15,8 @@
 //     layer boundaries as well: there IS no layer boundary.  The bias is the C operand of a job's first MFMA.
 //   * 64 POINTS PER WAVE (four point tiles of 16, one wave per SIMD): every A fragment (one ds_read_b128 per lane)
 //     feeds four MFMAs (64 matrix cycles), so LDS reads and the L2 -> LDS stream are half of the 32-points-per-wave
-//     design per FLOP (256 points per workgroup per pass over the 1.2 MB stream).
+//     design per FLOP (256 points per workgroup per pass over the 1.2 MB stream).  A second instantiation with 32 points
+//     per wave (NP = 2) serves launches too small to give every SIMD a 64-point unit (see NP below).
 //   * v_mfma_f32_16x16x32_bf16, not 32x32x16: the kernel is POWER limited (a build stripped to MFMAs + A-fragment
 //     reads runs at ~1.7 GHz, profiles/r02_bf16_ablation.json), and at equal cycles per FLOP the chip holds a higher
 //     clock on the 16x16x32 shape (tools/mfma_probe4.hip: +9 % FLOP/s for this operand pattern; MI355X_MICROARCH.md,
@@ -54,7 +55,10 @@ namespace minerf {
 
 typedef unsigned u32x4b __attribute__((ext_vector_type(4)));
 
-constexpr int NP = 4;                                      // point tiles (16 points each) per wave
+// Point tiles (16 points each) per wave: 4 in the standard shape (64 points per wave, 256 per workgroup and pass of the weight
+// stream), 2 in the SMALL-LAUNCH shape (32 / 128): twice the LDS reads and weight stream per FLOP, chosen by the launcher only
+// where the 64-point shape would leave SIMDs idle (a 512-ray shard of BASELINE config #5's 8-GPU split: 128 + 384 workgroup
+// passes on 256 CUs become 256 + 768 half-size ones).  NP is a template parameter of everything below.
 constexpr int MT = 16;                                     // output features per job
 constexpr int KF = 32;                                     // k per MFMA
 #ifdef MN_BF16_DA
@@ -66,7 +70,7 @@ constexpr int BSLOT_QUADS = 32;
 constexpr int BSLOT_BYTES = BSLOT_QUADS * QUAD_BYTES;      // 32 KiB
 constexpr int BNSLOT = 3;
 constexpr int BRING_BYTES = BNSLOT * BSLOT_BYTES;
-constexpr int BDMA = BSLOT_QUADS / 4;                      // DMAs per wave per slot
+__host__ __device__ constexpr int bdma_of(int nwv) { return BSLOT_QUADS / nwv; }      // DMAs per wave per slot (NWV waves per workgroup)
 constexpr int TAIL_USED = 128 + 8 + 64 + 4;                // quads of the tail body that carry weights
 constexpr int TAIL_QUADS = 224;                            // ... padded to whole slots
 
@@ -293,16 +297,19 @@ int pack_apply_bf16(const mi_nerf_net* net, const int32_t* map_dev, const float*
 // ---------------------------------------------------------------------------------------------
 // device
 // ---------------------------------------------------------------------------------------------
+struct PhaseB {
+    unsigned tile0, tile_end;   // this phase's range of 32-point tiles; tiles are numbered ray * tpr + chunk over the whole call
+    unsigned n_iter;            // units per wave (the same for every wave: the ring barriers are workgroup-wide); a unit = NP / 2 tiles
+    unsigned ppr;               // ray-major walk: units per ray (tpr / (NP / 2)); 0: flat walk
+};
 struct MlpArgsB {
     const char* stream;
     const float* side;
     const float* rays;
     const float* z;
     float* out;
-    unsigned n_wtiles;          // 32-point tiles (n_rays * tpr)
+    PhaseB ph[2];               // one or two phases (see run_phase); the kernel's template arguments say how many and of which shape
     unsigned n_rays;
-    unsigned n_iter;            // tile pairs per wave (the same for every wave: the ring barriers are workgroup-wide)
-    unsigned ppr;               // ray-major walk: pairs per ray (tpr / 2); 0: flat walk
     int S, tpr, D, skip_layer;
     unsigned stream_bytes, side_floats;
     unsigned o_bias_trunk, o_bias_feat, o_bias_d, o_head_b, o_wdir_t;
@@ -344,7 +351,9 @@ template <int IMM>
 __device__ __forceinline__ void bdma16(const char* gaddr_lane) {
     asm volatile("global_load_lds_dwordx4 %0, off offset:%1" ::"v"(gaddr_lane), "i"(IMM) : "memory");
 }
-// DMA number i (0..7) of the slot being fetched
+// DMA number i (0 .. BSLOT_QUADS / NWV - 1) of the slot being fetched: a wave's share of a slot is 8 KiB (4 waves per workgroup: two
+// 4 KiB halves, M0 set twice) or 4 KiB (8 waves)
+template <int NWV>
 __device__ __forceinline__ void bring_dma(const BRing& r, int i) {
 #ifdef MN_BF16_NODMA                                          // ablation builds (timing experiments only, results are garbage)
     return;
@@ -363,21 +372,24 @@ __device__ __forceinline__ void bring_next_fetch(BRing& r) {
     r.fetch_lds += BSLOT_BYTES;
     if (r.fetch_lds >= r.lds_hi) r.fetch_lds = r.lds_lo;
 }
-// consume the next slot: everything but the 8 DMAs issued during the phase that ends here has landed (slot p+1 was
+// consume the next slot: everything but the DMAs issued during the phase that ends here has landed (slot p+1 was
 // issued two phases ago); barrier; slot p+2 streams into ring[(p+2)%3] == ring[(p-1)%3] during the new phase.
 // Other vector-memory operations of the wave (input prefetches, result stores) share the counter and retire in order:
 // they can only make this wait stricter.
+template <int NWV>
 __device__ __forceinline__ void bring_advance(BRing& r) {
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if constexpr (NWV == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
 #ifndef MN_BF16_NOBARRIER
     __syncthreads();
 #endif
     bring_next_fetch(r);
     r.read_slot = (r.read_slot + 1 == BNSLOT) ? 0 : r.read_slot + 1;
 }
-// fragment at slot position qs; positions 1..8 also issue one of the slot's DMAs (never a burst)
+// fragment at slot position qs; positions 1 .. BSLOT_QUADS / NWV also issue one of the slot's DMAs (never a burst)
+template <int NWV>
 __device__ __forceinline__ u32x4b bring_read(const char* smem, const BRing& r, int lane, int qs) {
-    if (qs >= 1 && qs <= BDMA) bring_dma(r, qs - 1);
+    if (qs >= 1 && qs <= bdma_of(NWV)) bring_dma<NWV>(r, qs - 1);
     return *(const u32x4b*)(smem + r.read_slot * BSLOT_BYTES + lane * 16 + qs * QUAD_BYTES);
 }
 
@@ -391,8 +403,8 @@ __device__ __forceinline__ unsigned pack2(float lo, float hi) {
 // ---------------------------------------------------------------------------------------------
 // THE FRAGMENT FILE: all 256 AGPRs, managed by hand.
 //
-// Two sets (ping-pong between consecutive layers) x NP point tiles x 8 B fragments x 4 registers = 256 = the whole
-// accumulation-register file.  With most of the wave's 512 registers live, hipcc's allocator could not place these tuples
+// Two sets (ping-pong between consecutive layers) x NP point tiles x 8 B fragments x 4 registers = 256 (NP = 4) = the whole
+// accumulation-register file (half of it at NP = 2).  With most of the wave's 512 registers live, hipcc's allocator could not place these tuples
 // (it treats MFMA operands as "either file" values and thrashed: fragments copied AGPR -> VGPR in front of every MFMA,
 // accumulators spilled around the packing, up to 300 spilled registers) -- so the fragments never become compiler values at
 // all: they are written with v_accvgpr_write_b32 a[N] and read as the MFMA's B operand a[N:N+3] with N a compile-time
@@ -416,7 +428,7 @@ template <int B, int E, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (B < E) { f(IC<B>{}); static_for<B + 1, E>(f); }
 }
-__host__ __device__ constexpr int frag_reg(int set, int p, int f) { return ((set * NP + p) * 8 + f) * 4; }
+__host__ __device__ constexpr int frag_reg(int np, int set, int p, int f) { return ((set * np + p) * 8 + f) * 4; }
 
 // first MFMA of a job (C operand = bias) / accumulate; B operand from the fragment file (IC<R>) or from a VGPR fragment
 template <int R>
@@ -453,14 +465,24 @@ __device__ __forceinline__ void pack_whole(const f32x4& acc) {
     pack_stage<RELU, R, 0>(acc, t); pack_stage<RELU, R, 1>(acc, t); pack_stage<RELU, R, 2>(acc, t);
 }
 // register of the fragment file that receives tile T of a layer written into set SET, for point tile P
-__host__ __device__ constexpr int tile_reg(int set, int p, int t) { return frag_reg(set, p, t >> 1) + 2 * (t & 1); }
+__host__ __device__ constexpr int tile_reg(int np, int set, int p, int t) { return frag_reg(np, set, p, t >> 1) + 2 * (t & 1); }
 
-// The standard schedule of a job's packing work: the previous job's point tile pp is packed in group pp + 1, stages 0 / 1 / 2 in
-// the gaps behind MFMAs 1 / 2 / 3 (the gap behind MFMA 0 carries the ring bookkeeping).  Done by group 4: the half fragment
-// packed across a layer boundary feeds k-step 7.
-template <bool RELU, int SET, int T, int KS, int P>
-__device__ __forceinline__ void pack_sched(const f32x4 (&prev)[NP], unsigned (&t)[2]) {
-    if constexpr (KS >= 1 && KS <= NP && P >= 1) pack_stage<RELU, tile_reg(SET, KS - 1, T), P - 1>(prev[KS - 1], t);
+// The standard schedule of a job's packing work (jobs of >= 8 k-steps).  The gap behind MFMA 0 of a group carries the ring
+// bookkeeping, so packing rides in the other gaps.
+//   NP = 4: the previous job's point tile pp is packed in group pp + 1, stages 0 / 1 / 2 in the gaps behind MFMAs 1 / 2 / 3.
+//           Done by group 4.
+//   NP = 2: one gap per group: tile 0 in groups 1, 2, 3, tile 1 in groups 3, 4, 5 (group 3 carries two stages).  Done by group 5.
+// Either way the half fragment packed across a layer boundary (it feeds k-step 7) is written >= 2 MFMA issues before its reader,
+// and a tile's first stage is >= 5 MFMA issues (80 cycles) behind the MFMA that finished it.
+template <int NP, bool RELU, int SET, int T, int KS, int P>
+__device__ __forceinline__ void pack_sched(const f32x4 (&prev)[NP], unsigned (&t)[NP][2]) {
+    if constexpr (NP == 4) {
+        if constexpr (KS >= 1 && KS <= NP && P >= 1) pack_stage<RELU, tile_reg(NP, SET, KS - 1, T), P - 1>(prev[KS - 1], t[KS - 1]);
+    } else {
+        static_assert(NP == 2, "packing schedules exist for 4 and 2 point tiles per wave");
+        if constexpr (P == 1 && KS >= 1 && KS <= 3) pack_stage<RELU, tile_reg(NP, SET, 0, T), KS - 1>(prev[0], t[0]);
+        if constexpr (P == 1 && KS >= 3 && KS <= 5) pack_stage<RELU, tile_reg(NP, SET, 1, T), KS - 3>(prev[1], t[1]);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -472,7 +494,7 @@ __device__ __forceinline__ void pack_sched(const f32x4 (&prev)[NP], unsigned (&t
 // only ~two VALU instructions ride behind a 16-cycle MFMA before the wave blocks on the next one.
 // QEND/QPAD: stream positions >= QEND skip QPAD quads (the padding at the end of the tail body).
 // ---------------------------------------------------------------------------------------------
-template <int Q0, int KS, int QEND, int QPAD, typename CSel, typename BSrc, typename Hook>
+template <int NP, int NWV, int Q0, int KS, int QEND, int QPAD, typename CSel, typename BSrc, typename Hook>
 __device__ __forceinline__ void job(f32x4 (&acc)[NP], CSel csel, BSrc bsrc, u32x4b (&a)[DA], const char* smem, BRing& ring, int lane, Hook hook) {
     static_for<0, KS>([&](auto ks_c) __attribute__((always_inline)) {
         constexpr int ks = decltype(ks_c)::value;
@@ -483,8 +505,8 @@ __device__ __forceinline__ void job(f32x4 (&acc)[NP], CSel csel, BSrc bsrc, u32x
             if constexpr (ks == 0) mfma_first(acc[p], a[(Q0 + ks) % DA], bsrc(p_c, ks_c), csel(p));
             else mfma_acc(acc[p], a[(Q0 + ks) % DA], bsrc(p_c, ks_c));
             if constexpr (p == 0) {
-                if constexpr (qn % BSLOT_QUADS == 0) bring_advance(ring);
-                a[q0 % DA] = bring_read(smem, ring, lane, qn % BSLOT_QUADS);
+                if constexpr (qn % BSLOT_QUADS == 0) bring_advance<NWV>(ring);
+                a[q0 % DA] = bring_read<NWV>(smem, ring, lane, qn % BSLOT_QUADS);
             }
             hook(ks_c, p_c);
             asm volatile("" ::: "memory");
@@ -492,80 +514,66 @@ __device__ __forceinline__ void job(f32x4 (&acc)[NP], CSel csel, BSrc bsrc, u32x
         });
         // the C operands are dead for the compiler once the first MFMAs are issued, but the matrix pipe reads them for a few more
         // cycles: keep their registers out of the allocator's hands until the next group
-        if constexpr (ks == 0) { asm volatile("" ::"v"(csel(0)), "v"(csel(1))); asm volatile("" ::"v"(csel(2)), "v"(csel(3))); }
+        if constexpr (ks == 0) {
+            asm volatile("" ::"v"(csel(0)), "v"(csel(1)));
+            if constexpr (NP == 4) asm volatile("" ::"v"(csel(2)), "v"(csel(3)));
+        }
     });
 }
 
-template <int W, int LX, int LD>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
-void mlp_bf16_kernel(const MlpArgsB a) {
-    static_assert(W == 256, "bf16 variant: W = 256");
+// One PHASE of a launch: ph.n_iter units of NP point tiles per wave over the tiles [ph.tile0, ph.tile_end).  A launch is one phase
+// (one shape) or two (whole rounds of the 64-point shape, then the remainder as one round of the 32-point shape): the weight
+// ring and the A-fragment pipeline run on across the phase boundary (every unit ends at stream position 0).
+template <int W, int LX, int LD, int NP, int NWV>
+__device__ __forceinline__ void run_phase(const MlpArgsB& a, const PhaseB ph, char* smem, float* side, float* scr_base, char* pe_base, BRing& ring,
+                                          u32x4b (&aq)[DA], const int lane, const int wave
+#ifdef MN_DIAG
+                                          , unsigned long long (&seg)[8], unsigned long long& tprev
+#endif
+                                          ) {
     constexpr int NT = W / MT, KH = W / KF, KPE = enc_ksteps32(LX), IN_X = 3 + 6 * LX, IN_D = 3 + 6 * LD;
-    static_assert(KPE == 2 && NT == 16 && KH == 8 && NP == 4, "stream positions and the fragment file are laid out for 63 -> 64 encoded channels, W = 256, 4 point tiles");
+    constexpr int NTL = NP / 2;                              // 32-sample tiles per unit of work (point tile p: tile p >> 1, half p & 1)
+    static_assert(KPE == 2 && NT == 16 && KH == 8 && (NP == 4 || NP == 2), "stream positions and the fragment file are laid out for 63 -> 64 encoded channels, W = 256, 4 or 2 point tiles");
     constexpr int BIG = 1 << 30;
-    asm volatile("" ::: "a255");                             // reserve the whole accumulation-register file (see THE FRAGMENT FILE)
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* side = (float*)(smem + BRING_BYTES);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 15, q4 = lane >> 4;               // point of a 16-point tile; lane quarter
-    float* scratch = side + a.side_floats + wave * (2 * (W / 2));      // per wave, per 32-sample tile: hoisted direction bias
-    char* pe_wave = (char*)(side + a.side_floats + 4 * 2 * (W / 2)) + wave * (NP * KPE * QUAD_BYTES);   // this wave's parked gamma(x) fragments
+    const int pq = q4 & (NP - 1);                            // the point tile whose point `col` this lane encodes (NP = 2: quarters 2, 3 duplicate 0, 1)
+    float* scratch = scr_base + wave * (NTL * (W / 2));      // per wave, per 32-sample tile: hoisted direction bias
+    char* pe_wave = pe_base + wave * (NP * KPE * QUAD_BYTES);    // this wave's parked gamma(x) fragments
     char* pe_lds = pe_wave + lane * 16;
-    for (unsigned i = tid * 4; i < a.side_floats; i += 256 * 4) *(f32x4*)(side + i) = *(const f32x4*)(a.side + i);
-
-    BRing ring;
-    ring.sbase = a.stream + wave * (BDMA * QUAD_BYTES);
-    ring.voff = lane * 16;
-    ring.fetch_off = 0;
-    ring.stream_bytes = a.stream_bytes;
-    ring.lds_lo = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + wave * (BDMA * QUAD_BYTES);
-    ring.lds_hi = ring.lds_lo + BRING_BYTES;
-    ring.fetch_lds = ring.lds_lo;
-    ring.read_slot = BNSLOT - 1;
-#pragma unroll
-    for (int i = 0; i < BDMA; ++i) bring_dma(ring, i);       // slot 0
-    bring_next_fetch(ring);
-#pragma unroll
-    for (int i = 0; i < BDMA; ++i) bring_dma(ring, i);       // slot 1; slot p+2 streams in while slot p is consumed
-
-    u32x4b aq[DA];
-    bring_advance(ring);                                     // also publishes the side tables (barrier)
-#pragma unroll
-    for (int i = 0; i < DA - 1; ++i) aq[i] = bring_read(smem, ring, lane, i);      // position q is read while group q - (DA - 1) computes
-
-    // ---- tile walk: a wave takes PAIRS of consecutive 32-sample tiles = four 16-point MFMA tiles (point tile p: 32-sample tile
-    // p >> 1, half p & 1).  Ray-major (ppr > 0): a wave walks whole rays, so the hoisted view-direction term is computed once per
-    // ray; flat otherwise.  Inputs of the next pair are loaded a pair ahead.
-    const unsigned NW = gridDim.x * 4, wid = blockIdx.x * 4 + wave;
+    // ---- tile walk: a wave takes UNITS of NTL consecutive 32-sample tiles = NP 16-point MFMA tiles (point tile p: 32-sample tile
+    // p >> 1, half p & 1; a pair of tiles at NP = 4, one tile at NP = 2).  Ray-major (ppr > 0): a wave walks whole rays, so the
+    // hoisted view-direction term is computed once per ray; flat otherwise.  Inputs of the next unit are loaded a unit ahead.
+    const unsigned NW = gridDim.x * NWV, wid = blockIdx.x * NWV + wave;
     auto pair_of = [&](unsigned it) -> unsigned {
-        if (a.ppr) { const unsigned blk = it / a.ppr; return (blk * NW + wid) * a.ppr + (it - blk * a.ppr); }
+        if (ph.ppr) { const unsigned blk = it / ph.ppr; return (blk * NW + wid) * ph.ppr + (it - blk * ph.ppr); }
         return it * NW + wid;
     };
     // gamma(x) is computed ONCE per point: lane (q4, col) owns point `col` of point tile q4 (32-sample tile q4 >> 1, half q4 & 1),
     // encodes it and writes its fragments' dwords where the other lane quarters read them (the fragments are parked in LDS for the
     // skip layer anyway).  Each lane therefore loads one depth; the rays of both 32-sample tiles are loaded by every lane (the
     // hoisted view-direction term is computed per tile by the whole wave).
-    unsigned n_tile[2];  float nx_r[2][6], nx_z;
+    unsigned n_tile[NTL];  float nx_r[NTL][6], nx_z;
     auto load_inputs = [&](unsigned it) __attribute__((always_inline)) {
         const unsigned pr = pair_of(it);
 #pragma unroll
-        for (int tl = 0; tl < 2; ++tl) {
-            unsigned t = 2u * pr + tl;
+        for (int tl = 0; tl < NTL; ++tl) {
+            unsigned t = ph.tile0 + (unsigned)NTL * pr + tl;
             n_tile[tl] = t;
-            if (t >= a.n_wtiles) t = a.n_wtiles - 1;            // inactive: recompute the last tile, store nothing
+            if (t >= ph.tile_end) t = ph.tile_end - 1;            // inactive: recompute the last tile, store nothing
             const unsigned ray = t / (unsigned)a.tpr, chunk = t - ray * (unsigned)a.tpr;
             const float* rp = a.rays + (size_t)ray * 6;
 #pragma unroll
             for (int e = 0; e < 6; ++e) nx_r[tl][e] = rp[e];
-            if (tl == (q4 >> 1)) {
-                const int sample = (int)chunk * 32 + 16 * (q4 & 1) + col;
+            if (tl == (pq >> 1)) {
+                const int sample = (int)chunk * 32 + 16 * (pq & 1) + col;
                 nx_z = a.z[(size_t)ray * a.S + (sample < a.S ? sample : a.S - 1)];
             }
         }
     };
     load_inputs(0);
-    unsigned bias_ray[2] = {~0u, ~0u};
+    unsigned bias_ray[NTL];
+#pragma unroll
+    for (int tl = 0; tl < NTL; ++tl) bias_ray[tl] = ~0u;
 
     f32x4 acc[NP], prev[NP];
     f32x4 cin, cnext;                                        // bias of the current / next job (shared by the point tiles)
@@ -585,16 +593,16 @@ void mlp_bf16_kernel(const MlpArgsB a) {
         auto bsrc = [&](auto p_c, auto ks_c) __attribute__((always_inline)) -> decltype(auto) {
             constexpr int p = decltype(p_c)::value, ks = decltype(ks_c)::value;
             if constexpr (ks >= KH) return (const u32x4b&)per[p][ks - KH];
-            else return IC<frag_reg(SIN, p, ks)>{};
+            else return IC<frag_reg(NP, SIN, p, ks)>{};
         };
         static_for<0, NT>([&](auto t_c) __attribute__((always_inline)) {
             constexpr int t = decltype(t_c)::value;
-            unsigned pt[2];
+            unsigned pt[NP][2];
             auto hook = [&](auto ks_c, auto p_c) __attribute__((always_inline)) {
                 constexpr int ks = decltype(ks_c)::value, p = decltype(p_c)::value;
                 // previous tile -> (half a) fragment of the layer that follows it
-                if constexpr (t == 0) pack_sched<true, SIN, NT - 1, ks, p>(prev, pt);
-                else pack_sched<true, SOUT, t - 1, ks, p>(prev, pt);
+                if constexpr (t == 0) pack_sched<NP, true, SIN, NT - 1, ks, p>(prev, pt);
+                else pack_sched<NP, true, SOUT, t - 1, ks, p>(prev, pt);
                 if constexpr (ks == 5 && p == 1) {              // bias of the next job (C operand of its first MFMAs)
                     const float* v = (t + 1 < NT) ? bias + MT * (t + 1) + 4 * q4 : next_bias + 4 * q4;
                     cnext = *(const f32x4*)v;
@@ -602,26 +610,22 @@ void mlp_bf16_kernel(const MlpArgsB a) {
                 if constexpr (SKIP && ks >= KH - 2 && ks < KH - 2 + KPE)         // gamma(x) fragment of k-step ks + 2, one point tile per gap
                     per[p][ks - (KH - 2)] = *(const u32x4b*)(pe_lds + (p * KPE + (ks - (KH - 2))) * QUAD_BYTES);
             };
-            job<t * KS, KS, BIG, 0>(acc, csel1, bsrc, aq, smem, ring, lane, hook);
+            job<NP, NWV, t * KS, KS, BIG, 0>(acc, csel1, bsrc, aq, smem, ring, lane, hook);
 #pragma unroll
             for (int p = 0; p < NP; ++p) prev[p] = acc[p];
             cin = cnext;
         });
     };
 
-#ifdef MN_DIAG
-    unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long tprev = bstamp();
-#endif
-    for (unsigned it = 0; it < a.n_iter; ++it) {
+    for (unsigned it = 0; it < ph.n_iter; ++it) {
         // ---- prologue: this pair's points, gamma(x) fragments, hoisted view-direction bias ------------------------------------
-        unsigned tray[2]; bool valid[NP]; size_t out_idx[NP];
-        float in_o[2][3], in_d[2][3];
+        unsigned tray[NTL]; bool valid[NP]; size_t out_idx[NP];
+        float in_o[NTL][3], in_d[NTL][3];
         const float in_z = nx_z;
 #pragma unroll
-        for (int tl = 0; tl < 2; ++tl) {
-            const bool active = n_tile[tl] < a.n_wtiles;
-            const unsigned t = active ? n_tile[tl] : a.n_wtiles - 1;
+        for (int tl = 0; tl < NTL; ++tl) {
+            const bool active = n_tile[tl] < ph.tile_end;
+            const unsigned t = active ? n_tile[tl] : ph.tile_end - 1;
             const unsigned ray = t / (unsigned)a.tpr, chunk = t - ray * (unsigned)a.tpr;
             tray[tl] = ray;
 #pragma unroll
@@ -634,11 +638,13 @@ void mlp_bf16_kernel(const MlpArgsB a) {
             for (int e = 0; e < 3; ++e) { in_o[tl][e] = nx_r[tl][e]; in_d[tl][e] = nx_r[tl][3 + e]; }
         }
         {
-            const bool t1 = (q4 >> 1) != 0;                     // this lane's point belongs to the second 32-sample tile
+            const bool t1 = (pq >> 1) != 0;                     // this lane's point belongs to the second 32-sample tile (NP = 4 only)
+            auto mine = [&](const float (&v)[NTL][3], int c) __attribute__((always_inline)) -> float {
+                if constexpr (NTL == 2) return t1 ? v[1][c] : v[0][c];
+                else return v[0][c];
+            };
             // pts = rays_o + rays_d * z (nerf_process.py:69-70)
-            const float pt[3] = {(t1 ? in_o[1][0] : in_o[0][0]) + (t1 ? in_d[1][0] : in_d[0][0]) * in_z,
-                                 (t1 ? in_o[1][1] : in_o[0][1]) + (t1 ? in_d[1][1] : in_d[0][1]) * in_z,
-                                 (t1 ? in_o[1][2] : in_o[0][2]) + (t1 ? in_d[1][2] : in_d[0][2]) * in_z};
+            const float pt[3] = {mine(in_o, 0) + mine(in_d, 0) * in_z, mine(in_o, 1) + mine(in_d, 1) * in_z, mine(in_o, 2) + mine(in_d, 2) * in_z};
             float sn[LX][3], cs[LX][3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -664,9 +670,10 @@ void mlp_bf16_kernel(const MlpArgsB a) {
                 const int k = (u - 3) / 6, r = (u - 3) % 6;
                 return r < 3 ? sn[k][r] : cs[k][r - 3];
             };
-            // fragment (point tile q4, k-step ks): lane quarter qq reads channels 32 ks + 8 qq + j of point `col` at
-            // [fragment][(qq * 16 + col) * 16 bytes]: this lane writes those 16 bytes for every qq
-            char* wr = pe_wave + (q4 * KPE) * QUAD_BYTES + col * 16;
+            // fragment (point tile pq, k-step ks): lane quarter qq reads channels 32 ks + 8 qq + j of point `col` at
+            // [fragment][(qq * 16 + col) * 16 bytes]: this lane writes those 16 bytes for every qq (at NP = 2 lane quarters 2, 3
+            // write what quarters 0, 1 write: same bytes, same addresses)
+            char* wr = pe_wave + (pq * KPE) * QUAD_BYTES + col * 16;
 #pragma unroll
             for (int ks = 0; ks < KPE; ++ks)
 #pragma unroll
@@ -684,11 +691,11 @@ void mlp_bf16_kernel(const MlpArgsB a) {
             for (int ks = 0; ks < KPE; ++ks) peb[p][ks] = *(const u32x4b*)(pe_lds + (p * KPE + ks) * QUAD_BYTES);
         // hoisted view-direction term of linear_d (fp32), per 32-sample tile: scratch[tl][n] = b_d[n] + sum_f Wd[n][W+f] * gamma(d/|d|)[f]
 #pragma unroll
-        for (int tl = 0; tl < 2; ++tl) {
+        for (int tl = 0; tl < NTL; ++tl) {
             float* sc_t = scratch + tl * (W / 2);
             if (tray[tl] != bias_ray[tl]) {
                 bias_ray[tl] = tray[tl];
-                if (tl == 1 && tray[1] == tray[0]) {            // both tiles on one ray: copy (same wave: no barrier needed)
+                if (tl == 1 && tray[NTL - 1] == tray[0]) {      // both tiles on one ray: copy (same wave: no barrier needed)
 #pragma unroll
                     for (int n0 = 0; n0 < W / 2; n0 += 64) sc_t[n0 + lane] = scratch[n0 + lane];
                 } else {
@@ -728,15 +735,20 @@ void mlp_bf16_kernel(const MlpArgsB a) {
                 constexpr int t = decltype(t_c)::value;
                 auto hook = [&](auto ks_c, auto p_c) __attribute__((always_inline)) {
                     constexpr int ks = decltype(ks_c)::value, p = decltype(p_c)::value;
-                    // 8 MFMAs per job and four tiles to pack: a whole statement per gap (these jobs run VALU bound; 3 % of the MFMAs)
-                    if constexpr (t > 0 && ks == 0 && p >= 1) pack_whole<true, tile_reg(0, p - 1, t - 1)>(prev[p - 1]);
-                    if constexpr (t > 0 && ks == 1 && p == 1) pack_whole<true, tile_reg(0, 3, t - 1)>(prev[3]);
-                    if constexpr (ks == 1 && p == 2) {
+                    // 2 NP MFMAs per job and NP tiles to pack: a whole statement per gap (these jobs run VALU bound; 3 % of the MFMAs).
+                    // A tile is packed >= 4 MFMA issues behind the MFMA that finished it.
+                    if constexpr (NP == 4) {
+                        if constexpr (t > 0 && ks == 0 && p >= 1) pack_whole<true, tile_reg(NP, 0, p - 1, t - 1)>(prev[p - 1]);
+                        if constexpr (t > 0 && ks == 1 && p == 1) pack_whole<true, tile_reg(NP, 0, 3, t - 1)>(prev[3]);
+                    } else {
+                        if constexpr (t > 0 && ks == 1) pack_whole<true, tile_reg(NP, 0, p, t - 1)>(prev[p]);
+                    }
+                    if constexpr ((NP == 4 && ks == 1 && p == 2) || (NP == 2 && ks == 0 && p == 1)) {
                         const float* v = (t + 1 < NT) ? b0 + MT * (t + 1) : side + a.o_bias_trunk + W + 4 * q4;
                         cnext = *(const f32x4*)v;
                     }
                 };
-                job<t * KPE, KPE, BIG, 0>(acc, csel1, bsrc, aq, smem, ring, lane, hook);
+                job<NP, NWV, t * KPE, KPE, BIG, 0>(acc, csel1, bsrc, aq, smem, ring, lane, hook);
 #pragma unroll
                 for (int p = 0; p < NP; ++p) prev[p] = acc[p];
                 cin = cnext;
@@ -767,16 +779,16 @@ void mlp_bf16_kernel(const MlpArgsB a) {
             auto cseld = [&](int p) __attribute__((always_inline)) -> const f32x4& { return cind[p]; };
             auto cselh = [&](int) __attribute__((always_inline)) -> const f32x4& { return cinh; };
             const float* bf = side + a.o_bias_feat + 4 * q4;
-            auto bsrc_in = [&](auto p_c, auto ks_c) __attribute__((always_inline)) { return IC<frag_reg(SIN, decltype(p_c)::value, decltype(ks_c)::value)>{}; };
-            auto bsrc_out = [&](auto p_c, auto ks_c) __attribute__((always_inline)) { return IC<frag_reg(SOUT, decltype(p_c)::value, decltype(ks_c)::value)>{}; };
+            auto bsrc_in = [&](auto p_c, auto ks_c) __attribute__((always_inline)) { return IC<frag_reg(NP, SIN, decltype(p_c)::value, decltype(ks_c)::value)>{}; };
+            auto bsrc_out = [&](auto p_c, auto ks_c) __attribute__((always_inline)) { return IC<frag_reg(NP, SOUT, decltype(p_c)::value, decltype(ks_c)::value)>{}; };
             // feature layer: no activation on its outputs; its first job still packs the trunk's last tile (ReLU)
             static_for<0, NT>([&](auto t_c) __attribute__((always_inline)) {
                 constexpr int t = decltype(t_c)::value;
-                unsigned pt[2];
+                unsigned pt[NP][2];
                 auto hook = [&](auto ks_c, auto p_c) __attribute__((always_inline)) {
                     constexpr int ks = decltype(ks_c)::value, p = decltype(p_c)::value;
-                    if constexpr (t == 0) pack_sched<true, SIN, NT - 1, ks, p>(prev, pt);
-                    else pack_sched<false, SOUT, t - 1, ks, p>(prev, pt);
+                    if constexpr (t == 0) pack_sched<NP, true, SIN, NT - 1, ks, p>(prev, pt);
+                    else pack_sched<NP, false, SOUT, t - 1, ks, p>(prev, pt);
                     if constexpr (ks == 5 && p == 1) {
                         if constexpr (t + 1 < NT) cnext = *(const f32x4*)(bf + MT * (t + 1));
                         else {                                          // density tile: row 3 = density bias (lane quarter 0 only)
@@ -785,20 +797,20 @@ void mlp_bf16_kernel(const MlpArgsB a) {
                         }
                     }
                 };
-                job<t * KH, KH, BIG, 0>(acc, csel1, bsrc_in, aq, smem, ring, lane, hook);
+                job<NP, NWV, t * KH, KH, BIG, 0>(acc, csel1, bsrc_in, aq, smem, ring, lane, hook);
 #pragma unroll
                 for (int p = 0; p < NP; ++p) prev[p] = acc[p];
                 cin = cnext;
             });
             // density tile over the trunk output (row 3); packs the feature layer's last tile; reads the direction bias of tile 0
             {
-                unsigned pt[2];
+                unsigned pt[NP][2];
                 auto hook = [&](auto ks_c, auto p_c) __attribute__((always_inline)) {
                     constexpr int ks = decltype(ks_c)::value, p = decltype(p_c)::value;
-                    pack_sched<false, SOUT, NT - 1, ks, p>(prev, pt);
+                    pack_sched<NP, false, SOUT, NT - 1, ks, p>(prev, pt);
                     if constexpr (ks == 5) cnextd[p] = *(const f32x4*)(scratch + (p >> 1) * (W / 2) + 4 * q4);
                 };
-                job<128, KH, BIG, 0>(hd, csel1, bsrc_in, aq, smem, ring, lane, hook);
+                job<NP, NWV, 128, KH, BIG, 0>(hd, csel1, bsrc_in, aq, smem, ring, lane, hook);
 #pragma unroll
                 for (int p = 0; p < NP; ++p) cind[p] = cnextd[p];
             }
@@ -806,13 +818,13 @@ void mlp_bf16_kernel(const MlpArgsB a) {
             // trunk output is dead once the density tile has run)
             static_for<0, NT / 2>([&](auto t_c) __attribute__((always_inline)) {
                 constexpr int t = decltype(t_c)::value;
-                unsigned pt[2];
+                unsigned pt[NP][2];
                 auto hook = [&](auto ks_c, auto p_c) __attribute__((always_inline)) {
                     constexpr int ks = decltype(ks_c)::value, p = decltype(p_c)::value;
-                    if constexpr (t > 0) pack_sched<true, SIN, t - 1, ks, p>(prev, pt);
+                    if constexpr (t > 0) pack_sched<NP, true, SIN, t - 1, ks, p>(prev, pt);
                     if constexpr (t == 0 && ks == 6)            // the density tile finished >= 24 MFMAs ago: keep its one useful register
                         asm volatile("v_mov_b32 %0, %1" : "=v"(dens[p]) : "v"(hd[p][3]));
-                    if constexpr (t == 2 && ks == 6 && p == 1) load_inputs(it + 1 < a.n_iter ? it + 1 : it);      // next pair's rays and depths, ~3000 cycles ahead
+                    if constexpr (t == 2 && ks == 6 && p == 1) load_inputs(it + 1 < ph.n_iter ? it + 1 : it);      // next pair's rays and depths, ~3000 cycles ahead
                     if constexpr (ks == 5) {
                         if constexpr (t + 1 < NT / 2) cnextd[p] = *(const f32x4*)(scratch + (p >> 1) * (W / 2) + MT * (t + 1) + 4 * q4);
                         else if constexpr (p == 1) {                    // colour tile: rows 0..2 = colour bias (lane quarter 0 only)
@@ -821,7 +833,7 @@ void mlp_bf16_kernel(const MlpArgsB a) {
                         }
                     }
                 };
-                job<136 + t * KH, KH, BIG, 0>(acc, cseld, bsrc_out, aq, smem, ring, lane, hook);
+                job<NP, NWV, 136 + t * KH, KH, BIG, 0>(acc, cseld, bsrc_out, aq, smem, ring, lane, hook);
 #pragma unroll
                 for (int p = 0; p < NP; ++p) { prev[p] = acc[p]; cind[p] = cnextd[p]; }
             });
@@ -830,10 +842,14 @@ void mlp_bf16_kernel(const MlpArgsB a) {
             {
                 auto hook = [&](auto ks_c, auto p_c) __attribute__((always_inline)) {
                     constexpr int ks = decltype(ks_c)::value, p = decltype(p_c)::value;
-                    if constexpr (ks == 0 && p >= 1) pack_whole<true, tile_reg(SIN, p - 1, NT / 2 - 1)>(prev[p - 1]);
-                    if constexpr (ks == 1 && p == 1) pack_whole<true, tile_reg(SIN, 3, NT / 2 - 1)>(prev[3]);
+                    if constexpr (NP == 4) {
+                        if constexpr (ks == 0 && p >= 1) pack_whole<true, tile_reg(NP, SIN, p - 1, NT / 2 - 1)>(prev[p - 1]);
+                        if constexpr (ks == 1 && p == 1) pack_whole<true, tile_reg(NP, SIN, 3, NT / 2 - 1)>(prev[3]);
+                    } else {                                    // >= 4 MFMA issues behind the tile's last MFMA, two groups ahead of k-step 3
+                        if constexpr (ks == 1) pack_whole<true, tile_reg(NP, SIN, p, NT / 2 - 1)>(prev[p]);
+                    }
                 };
-                job<200, KH / 2, TAIL_USED, TAIL_QUADS - TAIL_USED>(hc, cselh, bsrc_in, aq, smem, ring, lane, hook);
+                job<NP, NWV, 200, KH / 2, TAIL_USED, TAIL_QUADS - TAIL_USED>(hc, cselh, bsrc_in, aq, smem, ring, lane, hook);
             }
             // the MFMAs are asm statements: hipcc does not know that `hc` is still in flight (XDL write -> vector-memory read)
             asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
@@ -848,9 +864,60 @@ void mlp_bf16_kernel(const MlpArgsB a) {
         else { BSTAMP(2); tail(IC<0>{}); }
         BSTAMP(3);   // tail
     }
+}
+
+// NWV waves per workgroup: 4 (one wave per SIMD: the 64-point shape needs the whole register file) or 8 (two waves per SIMD, 32-point
+// shape only: 120 VGPRs + the 128 AGPRs of its fragment file fit twice; the partner wave's MFMAs fill the issue slots a wave loses
+// to its DMA issues, packing and LDS waits, at the 64-point shape's 256 points per pass of the weight stream).
+template <int W, int LX, int LD, int NPA, int NPB, int NWV>
+__global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(NWV / 4, NWV / 4)))
+void mlp_bf16_kernel(const MlpArgsB a) {
+    static_assert(W == 256, "bf16 variant: W = 256");
+    static_assert(NWV == 4 || (NWV == 8 && NPA == 2 && NPB == 0), "two waves per SIMD: the 32-point shape only");
+    constexpr int NPM = NPA > NPB ? NPA : NPB;
+    // reserve the fragment file (see THE FRAGMENT FILE): the whole accumulation-register file, or its lower half
+    if constexpr (NWV == 4) asm volatile("" ::: "a255");
+    else asm volatile("" ::: "a127");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* side = (float*)(smem + BRING_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (unsigned i = tid * 4; i < a.side_floats; i += 64 * NWV * 4) *(f32x4*)(side + i) = *(const f32x4*)(a.side + i);
+    float* scr_base = side + a.side_floats;
+    char* pe_base = (char*)(scr_base + NWV * (NPM / 2) * (W / 2));
+
+    BRing ring;
+    ring.sbase = a.stream + wave * (bdma_of(NWV) * QUAD_BYTES);
+    ring.voff = lane * 16;
+    ring.fetch_off = 0;
+    ring.stream_bytes = a.stream_bytes;
+    ring.lds_lo = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + wave * (bdma_of(NWV) * QUAD_BYTES);
+    ring.lds_hi = ring.lds_lo + BRING_BYTES;
+    ring.fetch_lds = ring.lds_lo;
+    ring.read_slot = BNSLOT - 1;
+#pragma unroll
+    for (int i = 0; i < bdma_of(NWV); ++i) bring_dma<NWV>(ring, i);       // slot 0
+    bring_next_fetch(ring);
+#pragma unroll
+    for (int i = 0; i < bdma_of(NWV); ++i) bring_dma<NWV>(ring, i);       // slot 1; slot p+2 streams in while slot p is consumed
+
+    u32x4b aq[DA];
+    bring_advance<NWV>(ring);                                // also publishes the side tables (barrier)
+#pragma unroll
+    for (int i = 0; i < DA - 1; ++i) aq[i] = bring_read<NWV>(smem, ring, lane, i);      // position q is read while group q - (DA - 1) computes
+
+#ifdef MN_DIAG
+    unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = bstamp();
+    run_phase<W, LX, LD, NPA, NWV>(a, a.ph[0], smem, side, scr_base, pe_base, ring, aq, lane, wave, seg, tprev);
+    if constexpr (NPB != 0) run_phase<W, LX, LD, NPB, NWV>(a, a.ph[1], smem, side, scr_base, pe_base, ring, aq, lane, wave, seg, tprev);
+#else
+    run_phase<W, LX, LD, NPA, NWV>(a, a.ph[0], smem, side, scr_base, pe_base, ring, aq, lane, wave);
+    if constexpr (NPB != 0) run_phase<W, LX, LD, NPB, NWV>(a, a.ph[1], smem, side, scr_base, pe_base, ring, aq, lane, wave);
+#endif
 #ifdef MN_DIAG
     if (a.diag && lane == 0) {
-        unsigned long long* d = a.diag + ((size_t)blockIdx.x * 4 + wave) * 8;
+        unsigned long long* d = a.diag + ((size_t)blockIdx.x * NWV + wave) * 8;
         for (int i = 0; i < 8; ++i) d[i] = seg[i];
     }
 #endif
@@ -858,10 +925,83 @@ void mlp_bf16_kernel(const MlpArgsB a) {
     __syncthreads();
 }
 
+// The walk of one phase: shape NP over the tiles [tile0, tile_end) on a grid of `grid` workgroups.
+template <int NP, int NWV>
+static PhaseB make_phase(const MlpArgsB& a, long long tile0, long long tile_end, int grid) {
+    constexpr int NTL = NP / 2;
+    PhaseB ph{};
+    ph.tile0 = (unsigned)tile0; ph.tile_end = (unsigned)tile_end;
+    const long long NW = (long long)grid * NWV;
+    const long long n_units = (tile_end - tile0 + NTL - 1) / NTL;
+    const long long n_rays = (tile_end + a.tpr - 1) / a.tpr;     // rays this phase touches when it starts at tile 0
+    const long long it_flat = (n_units + NW - 1) / NW, it_ray = ((n_rays + NW - 1) / NW) * (a.tpr / NTL);
+    if (tile0 == 0 && a.tpr % NTL == 0 && n_rays >= NW && it_ray <= it_flat) {
+        ph.ppr = (unsigned)(a.tpr / NTL);                    // ray-major: every wave gets whole rays (tiles >= tile_end are skipped), unless
+        ph.n_iter = (unsigned)it_ray;                        // dealing whole rays would cost a round more than dealing units
+    } else {
+        ph.ppr = 0;
+        ph.n_iter = (unsigned)it_flat;
+    }
+    return ph;
+}
+
+// One launch: phase A of shape NPA over [0, split), then (NPB != 0) phase B of shape NPB over [split, n_wtiles).
+template <int NPA, int NPB, int NWV>
+static int launch_bf16(MlpArgsB a, long long split, long long n_wtiles, hipStream_t st) {
+    constexpr int NPM = NPA > NPB ? NPA : NPB;
+    const size_t lds = BRING_BYTES + (size_t)a.side_floats * 4 + (size_t)NWV * (NPM / 2) * (256 / 2) * 4 + (size_t)NWV * NPM * enc_ksteps32(10) * QUAD_BYTES;
+    MN_CHECK_ARG(lds <= 160 * 1024, "LDS budget exceeded: %zu bytes", lds);
+    auto kern = mlp_bf16_kernel<256, 10, 4, NPA, NPB, NWV>;
+    static LdsOptIn opt_in = {};
+    if (int rc = ensure_lds_opt_in(opt_in, (const void*)kern)) return rc;
+    const int n_cus = device_cus();
+    const long long wg_a = ((split + NPA / 2 - 1) / (NPA / 2) + NWV - 1) / NWV;
+    const long long wg_b = NPB ? ((n_wtiles - split + NPB / 2 - 1) / (NPB / 2) + NWV - 1) / NWV : 0;
+    const long long n_wg = wg_a > wg_b ? wg_a : wg_b;
+    const int grid = (int)(n_wg < n_cus ? n_wg : n_cus);
+    a.ph[0] = make_phase<NPA, NWV>(a, 0, split, grid);
+    if constexpr (NPB != 0) a.ph[1] = make_phase<NPB, NWV>(a, split, n_wtiles, grid);
+#ifdef MN_DIAG
+    {   // diagnostic build: run once with stamps and print the per-segment averages (cycles per unit per wave; single-phase launches)
+        unsigned long long* dbuf = nullptr;
+        const size_t n = (size_t)grid * NWV * 8;
+        MN_HIP(hipMalloc(&dbuf, n * 8));
+        MN_HIP(hipMemsetAsync(dbuf, 0, n * 8, st));
+        a.diag = dbuf;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NWV), lds, st, a);
+        MN_HIP(hipStreamSynchronize(st));
+        std::vector<unsigned long long> hbuf(n);
+        MN_HIP(hipMemcpy(hbuf.data(), dbuf, n * 8, hipMemcpyDeviceToHost));
+        (void)hipFree(dbuf);
+        static const char* names[4] = {"prologue", "layer0", "trunk", "tail"};
+        const double ideal[4] = {0, 512.0 * NPA, (7 * 2048 + 512.0) * NPA, 204 * 16.0 * NPA};
+        double tot = 0;
+        const unsigned n_iter = a.ph[0].n_iter + (NPB ? a.ph[1].n_iter : 0);
+        fprintf(stderr, "[mn_diag bf16] NP=%d(+%d) grid=%d units/wave=%u  cycles per unit (mean over waves; ideal MFMA cycles of the first shape in brackets):\n",
+                NPA, NPB, grid, n_iter);
+        for (int sgi = 0; sgi < 4; ++sgi) {
+            double sum = 0;
+            for (size_t w = 0; w < (size_t)grid * NWV; ++w) sum += (double)hbuf[w * 8 + sgi];
+            const double per = sum / ((double)grid * NWV) / (double)n_iter;
+            tot += per;
+            fprintf(stderr, "[mn_diag bf16]   %-10s %10.0f  [%6.0f]\n", names[sgi], per, ideal[sgi]);
+        }
+        fprintf(stderr, "[mn_diag bf16]   %-10s %10.0f  [%6.0f]\n", "total", tot, ideal[1] + ideal[2] + ideal[3]);
+        return MI_NERF_OK;
+    }
+#endif
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NWV), lds, st, a);
+    MN_LAUNCH_CHECK("mlp_bf16_kernel");
+    return MI_NERF_OK;
+}
+
+// points_per_wave: 0 = chosen per launch (pick_np), 64 / 32 = forced (A/B measurements, parity tests of each shape)
 int mlp_rays_bf16(const mi_nerf_net* net, const void* packed_dev, const float* rays_dev, const float* z_dev, int64_t n_rays, int S,
-                  float* raw_dev, hipStream_t st) {
+                  float* raw_dev, hipStream_t st, int points_per_wave) {
     if (int rc = check_net_bf16(net)) return rc;
     MN_CHECK_ARG(n_rays >= 0 && S >= 1, "bad sizes n_rays=%lld S=%d", (long long)n_rays, S);
+    MN_CHECK_ARG(points_per_wave == 0 || points_per_wave == 32 || points_per_wave == 64 || points_per_wave == 832,
+                 "points_per_wave must be 0 (auto), 32, 64 or 832 (8 waves of 32) (got %d)", points_per_wave);
     if (n_rays == 0) return MI_NERF_OK;
     MN_CHECK_ARG(packed_dev && rays_dev && z_dev && raw_dev, "NULL device pointer");
     const BlobLayoutBf16 L = make_layout_bf16(net->D, net->W, net->skip, net->L_x, net->L_d);
@@ -872,58 +1012,33 @@ int mlp_rays_bf16(const mi_nerf_net* net, const void* packed_dev, const float* r
     a.S = S; a.tpr = (S + 31) / 32;
     const long long n_wtiles = (long long)n_rays * a.tpr;
     MN_CHECK_ARG(n_wtiles < (1LL << 30), "too many points for one launch: %lld rays x %d samples", (long long)n_rays, S);
-    a.n_wtiles = (unsigned)n_wtiles; a.n_rays = (unsigned)n_rays;
+    a.n_rays = (unsigned)n_rays;
     a.D = net->D;
     a.skip_layer = (net->skip >= 0 && net->skip + 1 < net->D) ? net->skip + 1 : -1;
     a.stream_bytes = L.stream_bytes; a.side_floats = L.side_floats;
     a.o_bias_trunk = L.bias_trunk; a.o_bias_feat = L.bias_feat; a.o_bias_d = L.bias_d; a.o_head_b = L.head_b; a.o_wdir_t = L.wdir_t;
-    const size_t lds = BRING_BYTES + (size_t)a.side_floats * 4 + 4 * 2 * (256 / 2) * 4 + 4 * NP * enc_ksteps32(10) * QUAD_BYTES;
-    MN_CHECK_ARG(lds <= 160 * 1024, "LDS budget exceeded: %zu bytes", lds);
-    auto kern = mlp_bf16_kernel<256, 10, 4>;
-    static LdsOptIn opt_in = {};
-    if (int rc = ensure_lds_opt_in(opt_in, (const void*)kern)) return rc;
-    const int n_cus = device_cus();
-    const long long n_pairs = (n_wtiles + 1) / 2;
-    const long long n_wg = (n_pairs + 3) / 4;
-    const int grid = (int)(n_wg < n_cus ? n_wg : n_cus);
-    const long long NW = (long long)grid * 4;
-    if (a.tpr % 2 == 0 && n_rays >= NW) {                    // ray-major: every wave gets whole rays
-        a.ppr = (unsigned)(a.tpr / 2);
-        a.n_iter = (unsigned)((n_rays + NW - 1) / NW) * a.ppr;
-    } else {
-        a.ppr = 0;
-        a.n_iter = (unsigned)((n_pairs + NW - 1) / NW);
-    }
-#ifdef MN_DIAG
-    {   // diagnostic build: run once with stamps and print the per-segment averages (cycles per tile PAIR per wave)
-        unsigned long long* dbuf = nullptr;
-        const size_t n = (size_t)grid * 4 * 8;
-        MN_HIP(hipMalloc(&dbuf, n * 8));
-        MN_HIP(hipMemsetAsync(dbuf, 0, n * 8, st));
-        a.diag = dbuf;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
-        MN_HIP(hipStreamSynchronize(st));
-        std::vector<unsigned long long> hbuf(n);
-        MN_HIP(hipMemcpy(hbuf.data(), dbuf, n * 8, hipMemcpyDeviceToHost));
-        (void)hipFree(dbuf);
-        static const char* names[4] = {"prologue", "layer0", "trunk", "tail"};
-        static const double ideal[4] = {0, 2048, 7 * 8192 + 2048, 204 * 64};
-        double tot = 0;
-        fprintf(stderr, "[mn_diag bf16] grid=%d pairs/wave=%u  cycles per pair (mean over waves; ideal MFMA cycles in brackets):\n", grid, a.n_iter);
-        for (int sgi = 0; sgi < 4; ++sgi) {
-            double sum = 0;
-            for (size_t w = 0; w < (size_t)grid * 4; ++w) sum += (double)hbuf[w * 8 + sgi];
-            const double per = sum / ((double)grid * 4) / (double)a.n_iter;
-            tot += per;
-            fprintf(stderr, "[mn_diag bf16]   %-10s %10.0f  [%6.0f]\n", names[sgi], per, ideal[sgi]);
-        }
-        fprintf(stderr, "[mn_diag bf16]   %-10s %10.0f  [%6.0f]\n", "total", tot, ideal[1] + ideal[2] + ideal[3]);
-        return MI_NERF_OK;
-    }
+    if (points_per_wave == 64) return launch_bf16<4, 0, 4>(a, n_wtiles, n_wtiles, st);
+    if (points_per_wave == 32) return launch_bf16<2, 0, 4>(a, n_wtiles, n_wtiles, st);
+#ifdef MN_BF16_NWV8        // A/B variant build only (python -m nerf_pytorch_paeng_amd.build --variant nwv8 -DMN_BF16_NWV8; tools/bf16_shape_probe.py):
+    // 8 waves of 32 points per workgroup, two waves per SIMD.  Measured SLOWER than the 64-point shape at every size (4096 rays: fine
+    // launch 638 vs 603 us, profiles/r03_bf16_two_waves_per_simd.txt): the kernel is not short of latency hiding, it is short of
+    // power -- twice the LDS reads per FLOP cost more clock than the interleaving wins back.  Not instantiated in the shipped library.
+    if (points_per_wave == 832) return launch_bf16<2, 0, 8>(a, n_wtiles, n_wtiles, st);
+#else
+    MN_CHECK_ARG(points_per_wave != 832, "the 8-wave shape (832) exists in -DMN_BF16_NWV8 variant builds only");
 #endif
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
-    MN_LAUNCH_CHECK("mlp_bf16_kernel");
-    return MI_NERF_OK;
+    // The launch plan.  A pass of the 64-point shape takes the same time whatever the number of active CUs (the kernel is bound by
+    // what ONE CU does per pass), a pass of the 32-point shape ~0.65 of it (half the matrix work, the same weight stream:
+    // profiles/r03_bf16_small_launch_shape.txt).  So: whole rounds of the 64-point shape (every wave of the chip a pair of tiles),
+    // then the remainder as ONE round of the 32-point shape if it fits one (every wave one tile), else as one more 64-point round;
+    // both phases in ONE launch (the weight ring streams on across the phase boundary).
+    // A 512-ray shard of BASELINE config #5 (8 GPUs): coarse 1024 tiles = one 32-point round (was half the chip for a full pass);
+    // fine 3072 tiles = one 64-point round + one 32-point round (was two full passes, the second half empty).
+    const long long round4 = (long long)device_cus() * 4 * 2, round2 = (long long)device_cus() * 4;
+    const long long main_tiles = (n_wtiles / round4) * round4, rem = n_wtiles - main_tiles;
+    if (rem == 0 || rem > round2) return launch_bf16<4, 0, 4>(a, n_wtiles, n_wtiles, st);
+    if (main_tiles == 0) return launch_bf16<2, 0, 4>(a, n_wtiles, n_wtiles, st);
+    return launch_bf16<4, 2, 4>(a, main_tiles, n_wtiles, st);
 }
 
 }  // namespace minerf

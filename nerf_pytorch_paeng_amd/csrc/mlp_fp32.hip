@@ -386,7 +386,10 @@ static int launch(const MlpArgs& args_in, long long n_wtiles, hipStream_t st) {
 #ifdef MN_NO_RAY_MAJOR
         args.ray_major = 0;                                  // A/B variant (tools/ab_probe.py)
 #else
-        args.ray_major = (MODE == 0 && args.n_rays >= NW) ? 1 : 0;
+        // ... and dealing whole rays does not cost a round more than dealing tiles (1500 rays x 6 tiles on 1024 waves: 12 steps
+        // ray-major, 9 tile-major)
+        const long long it_ray = (args.n_rays + NW - 1) / NW * args.tpr, it_flat = (n_wg + grid - 1) / grid;
+        args.ray_major = (MODE == 0 && args.n_rays >= NW && it_ray <= it_flat) ? 1 : 0;
 #endif
         if (args.ray_major) {
             args.walk_ray = 0; args.walk_chunk = 1; args.walk_carry = NW;

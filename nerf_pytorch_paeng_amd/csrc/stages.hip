@@ -105,15 +105,28 @@ __device__ __forceinline__ float strat_edge(int i, int S, float step, float near
     return near_ * (1.0f - t) + far_ * t;               // nerf_process.py:53
 }
 
+// Where a stage's uniforms come from: an explicit [n, S] tensor (injected randomness: parity tests, the training path), or -- values ==
+// NULL -- the counter-based generator evaluated in the consuming kernel itself, keyed on (seed, stream, ray0 + ray, sample): the
+// values mi_nerf_fill_uniform would have written, without the tensor, its launch or its HBM round trip.
+struct Jitter {
+    const float* values;
+    uint32_t seed, stream;
+    long long ray0;
+};
+__device__ __forceinline__ float jitter_at(const Jitter& j, long long ray, int sample, int S) {
+    return j.values ? j.values[ray * S + sample] : counter_uniform(j.seed, j.stream, (uint32_t)(j.ray0 + ray), (uint32_t)sample);
+}
+
 __global__ __launch_bounds__(256) void stratified_kernel(long long total, int S, float near_, float far_, float step,
-                                                          const float* __restrict__ t_rand, float* __restrict__ z) {
+                                                          Jitter t_rand, float* __restrict__ z) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
-    const int i = (int)(idx % S);
+    const long long ray = idx / S;
+    const int i = (int)(idx - ray * S);
     const float zi = strat_edge(i, S, step, near_, far_);
     const float lower = (i == 0) ? zi : 0.5f * (zi + strat_edge(i - 1, S, step, near_, far_));       // :55,57
     const float upper = (i == S - 1) ? zi : 0.5f * (strat_edge(i + 1, S, step, near_, far_) + zi);   // :55,56
-    z[idx] = lower + (upper - lower) * t_rand[idx];     // :60
+    z[idx] = lower + (upper - lower) * jitter_at(t_rand, ray, i, S);     // :60
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -456,10 +469,70 @@ __global__ __launch_bounds__(256) void sample_pdf_kernel(const float* __restrict
     }
 }
 
+// Bitonic sorting network over n2 = 64 R values held R per lane (v[r] = element R * lane + r; no NaNs), ascending.  A compare-exchange
+// whose partner lies among the lane's own R elements is a register operation; the others fetch the partner lane's register through
+// ds_bpermute (__shfl_xor) -- no LDS array, no fence per stage.  64 + 128 depths (R = 4): 15 in-lane and 21 cross-lane stages.
+template <int R>
+__device__ __forceinline__ void bitonic_sort_regs(float (&v)[R], int lane) {
+    constexpr int n2 = 64 * R;
+#pragma unroll
+    for (int k = 2; k <= n2; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= R) {
+                const int m = j / R;                                       // partner: the same register of lane ^ m
+                const bool lower = (lane & m) == 0;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const bool up = (((R * lane + r) & k) == 0);
+                    const float x = v[r], y = __shfl_xor(x, m, 64);
+                    const bool lt = x < y;
+                    const float lo = lt ? x : y, hi = lt ? y : x;
+                    v[r] = (lower == up) ? lo : hi;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    if ((r & j) == 0) {
+                        const bool up = (((R * lane + r) & k) == 0);
+                        const float x = v[r], y = v[r | j];
+                        const bool lt = x < y;
+                        const float lo = lt ? x : y, hi = lt ? y : x;
+                        v[r] = up ? lo : hi;
+                        v[r | j] = up ? hi : lo;
+                    }
+            }
+        }
+    }
+}
+// all[0 .. St) (this wave's LDS slice, complete and visible to the wave) -> z_f row, sorted, NaNs last
+template <int R>
+__device__ __forceinline__ void sort_row_regs(const float* all, int St, float* __restrict__ zrow, int lane) {
+    float v[R];
+    int nan_here = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int e = R * lane + r;
+        const float x = e < St ? all[e] : __builtin_inff();
+        const bool isn = x != x;
+        nan_here += isn ? 1 : 0;
+        v[r] = isn ? __builtin_inff() : x;
+    }
+    int n_nan = nan_here;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n_nan += __shfl_xor(n_nan, o, 64);
+    bitonic_sort_regs<R>(v, lane);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int e = R * lane + r;
+        if (e < St) zrow[e] = e < St - n_nan ? v[r] : __builtin_nanf("");
+    }
+}
+
 // fine branch: bins = mid(z_c), weights = weights_c[1:-1], then sort(cat(z_c, samples))   (:63-67)
 // wr: this ray's Sc coarse weights (global or LDS); lds: this wave's slice of 2 (Sc - 1) + n2 floats.
 __device__ __forceinline__ void fine_z_ray(const float* __restrict__ z_c, const float* wr, long long ray, int Sc, int Nf, int n2, int det,
-                                           const float* __restrict__ u, float* __restrict__ z_f, float* __restrict__ z_samp, float* lds,
+                                           const Jitter& u, float* __restrict__ z_f, float* __restrict__ z_samp, float* lds,
                                            int lane) {
     const int B = Sc - 1, St = Sc + Nf;
     float* cdf = lds;                                       // n2: Sc + Nf rounded up to a power of two (the sort network)
@@ -472,7 +545,7 @@ __device__ __forceinline__ void fine_z_ray(const float* __restrict__ z_c, const 
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     for (int j = lane; j < Nf; j += 64) {
-        const float uu = det ? det_u(j, Nf) : u[ray * Nf + j];
+        const float uu = det ? det_u(j, Nf) : jitter_at(u, ray, j, Nf);
         const float s = invert_cdf(cdf, bn, B, uu);
         all[Sc + j] = s;
         if (z_samp) z_samp[ray * Nf + j] = s;
@@ -484,7 +557,11 @@ __device__ __forceinline__ void fine_z_ray(const float* __restrict__ z_c, const 
     // n2/2 compare-exchanges (36 stages of 2 per lane for 64 + 128 samples; the rank sort this replaces did St compares for each
     // of St/64 elements per lane -- 48 k cycles per ray, 23 us per launch however few the rays).  NaN depths (a diverged
     // network: NaN weights -> NaN samples) are sorted as +inf and written back as NaN in the last slots, where torch.sort
-    // places them; every slot of z_f (torch.empty) is written.
+    // places them; every slot of z_f (torch.empty) is written.  Up to 512 depths the network runs in registers (bitonic_sort_regs).
+    if (n2 == 256) return sort_row_regs<4>(all, St, z_f + ray * St, lane);
+    if (n2 == 128) return sort_row_regs<2>(all, St, z_f + ray * St, lane);
+    if (n2 == 64) return sort_row_regs<1>(all, St, z_f + ray * St, lane);
+    if (n2 == 512) return sort_row_regs<8>(all, St, z_f + ray * St, lane);
     int nan_here = 0;
     for (int e = lane; e < n2; e += 64) {
         const float v = e < St ? all[e] : __builtin_inff();
@@ -516,13 +593,33 @@ __device__ __forceinline__ void fine_z_ray(const float* __restrict__ z_c, const 
 }
 
 __global__ __launch_bounds__(256) void fine_z_kernel(const float* __restrict__ z_c, const float* __restrict__ w_c, long long n,
-                                                      int Sc, int Nf, int n2, int det, const float* __restrict__ u,
+                                                      int Sc, int Nf, int n2, int det, Jitter u,
                                                       float* __restrict__ z_f, float* __restrict__ z_samp) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const long long ray = (long long)blockIdx.x * 4 + wv;
     if (ray >= n) return;
     fine_z_ray(z_c, w_c + ray * Sc, ray, Sc, Nf, n2, det, u, z_f, z_samp, lds + wv * (2 * (Sc - 1) + n2), lane);
+}
+
+// render_rays' middle (nerf_process.py:198-203) in ONE launch: composite the coarse pass, resample from its weights, merge-sort.  Both
+// halves are one wave per ray; the weights go from the compositing registers to the sampler through the wave's LDS slice (and to the
+// workspace, which the staged parity checks read).  At a 512-ray shard a launch is ~4 us of dispatch for ~1 us of work: the fused
+// kernel is one launch where there were two (three with the uniforms' own).
+template <int C>
+__global__ __launch_bounds__(256) void composite_fine_z_kernel(const float* __restrict__ raw, const float* __restrict__ z_c,
+                                                                const float* __restrict__ rays, long long n, int Sc, int Nf, int n2, int det,
+                                                                Jitter u, float* __restrict__ rgb_o, float* __restrict__ disp_o,
+                                                                float* __restrict__ w_o, float* __restrict__ z_f) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long long ray = (long long)blockIdx.x * 4 + wv;
+    if (ray >= n) return;
+    float* mine = lds + wv * (Sc + 2 * (Sc - 1) + n2);
+    composite_ray<C>(raw, z_c, rays, 6, ray, Sc, lane, rgb_o, disp_o, nullptr, w_o, nullptr, mine);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    fine_z_ray(z_c, mine, ray, Sc, Nf, n2, det, u, z_f, nullptr, mine + Sc, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -576,13 +673,15 @@ int stage_fill_uniform(uint32_t seed, uint32_t stream_id, int64_t ray0, int64_t 
     return MI_NERF_OK;
 }
 
-int stage_stratified(int64_t n_rays, int S, float near_, float far_, const float* t_rand, float* z, hipStream_t st) {
+// t_rand == NULL: the uniforms are drawn in the kernel from (seed, stream 0, ray0 + ray, sample)
+int stage_stratified(int64_t n_rays, int S, float near_, float far_, const float* t_rand, uint32_t seed, int64_t ray0, float* z, hipStream_t st) {
     MN_CHECK_ARG(n_rays >= 0 && S >= 1, "bad sizes");
     const long long total = (long long)n_rays * S;
     if (total == 0) return MI_NERF_OK;
-    MN_CHECK_ARG(t_rand && z, "NULL pointer");
+    MN_CHECK_ARG(z, "NULL pointer");
     const float step = S > 1 ? 1.0f / (float)(S - 1) : 0.0f;
-    hipLaunchKernelGGL(stratified_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, st, total, S, near_, far_, step, t_rand, z);
+    hipLaunchKernelGGL(stratified_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, st, total, S, near_, far_, step,
+                       Jitter{t_rand, seed, 0u, (long long)ray0}, z);
     MN_LAUNCH_CHECK("stratified_kernel");
     return MI_NERF_OK;
 }
@@ -653,8 +752,9 @@ int stage_sample_pdf(const float* bins, const float* weights, int64_t n, int B, 
     return MI_NERF_OK;
 }
 
-int stage_fine_z(const float* z_c, const float* w_c, int64_t n, int Sc, int Nf, int det, const float* u, float* z_f, float* z_samp,
-                 hipStream_t st) {
+// u == NULL (and not det): the uniforms are drawn in the kernel from (seed, stream 1, ray0 + ray, sample)
+int stage_fine_z(const float* z_c, const float* w_c, int64_t n, int Sc, int Nf, int det, const float* u, uint32_t seed, int64_t ray0,
+                 float* z_f, float* z_samp, hipStream_t st) {
     // 4 rays per block, 2(Sc-1) + pow2(Sc + Nf) floats each, within the 64 KB of dynamic LDS a launch gets without opting in
     MN_CHECK_ARG(n >= 0 && Sc >= 3 && Nf >= 1 && Sc + Nf <= MAX_LDS_FLOATS_PER_RAY, "bad sizes (Sc=%d Nf=%d)", Sc, Nf);
     int n2 = 2;
@@ -662,10 +762,33 @@ int stage_fine_z(const float* z_c, const float* w_c, int64_t n, int Sc, int Nf, 
     MN_CHECK_ARG(2 * (Sc - 1) + n2 <= MAX_LDS_FLOATS_PER_RAY, "bad sizes (Sc=%d Nf=%d: 2*(Sc-1) + %d (Sc+Nf rounded up to a power of two) must not exceed %d)",
                  Sc, Nf, n2, MAX_LDS_FLOATS_PER_RAY);
     if (n == 0) return MI_NERF_OK;
-    MN_CHECK_ARG(z_c && w_c && z_f && (det || u), "NULL pointer");
+    MN_CHECK_ARG(z_c && w_c && z_f, "NULL pointer");
     const size_t lds = (size_t)4 * (2 * (Sc - 1) + n2) * sizeof(float);
-    hipLaunchKernelGGL(fine_z_kernel, dim3(blocks_for(n, 4)), dim3(256), lds, st, z_c, w_c, (long long)n, Sc, Nf, n2, det, u, z_f, z_samp);
+    hipLaunchKernelGGL(fine_z_kernel, dim3(blocks_for(n, 4)), dim3(256), lds, st, z_c, w_c, (long long)n, Sc, Nf, n2, det,
+                       Jitter{u, seed, 1u, (long long)ray0}, z_f, z_samp);
     MN_LAUNCH_CHECK("fine_z_kernel");
+    return MI_NERF_OK;
+}
+
+// composite of the coarse pass + resampling + merge-sort in one launch (what mi_nerf_render_rays runs between its two network passes)
+int stage_composite_fine_z(const float* raw_c, const float* z_c, const float* rays, int64_t n, int Sc, int Nf, int det, const float* u,
+                           uint32_t seed, int64_t ray0, float* rgb_c, float* disp_c, float* w_c, float* z_f, hipStream_t st) {
+    MN_CHECK_ARG(n >= 0 && Sc >= 3 && Sc <= 1024 && Nf >= 1 && Sc + Nf <= MAX_LDS_FLOATS_PER_RAY, "bad sizes (Sc=%d Nf=%d)", Sc, Nf);
+    int n2 = 2;
+    while (n2 < Sc + Nf) n2 <<= 1;
+    MN_CHECK_ARG(Sc + 2 * (Sc - 1) + n2 <= MAX_LDS_FLOATS_PER_RAY, "bad sizes (Sc=%d Nf=%d: 3 Sc - 2 + %d must not exceed %d)", Sc, Nf, n2,
+                 MAX_LDS_FLOATS_PER_RAY);
+    if (n == 0) return MI_NERF_OK;
+    MN_CHECK_ARG(raw_c && z_c && rays && rgb_c && disp_c && w_c && z_f, "NULL pointer");
+    const size_t lds = (size_t)4 * (Sc + 2 * (Sc - 1) + n2) * sizeof(float);
+    const dim3 grid(blocks_for(n, 4)), block(256);
+    const Jitter j{u, seed, 1u, (long long)ray0};
+    const int C = (Sc + 63) / 64;
+#define MN_CFZ(CC) hipLaunchKernelGGL(composite_fine_z_kernel<CC>, grid, block, lds, st, raw_c, z_c, rays, (long long)n, Sc, Nf, n2, det, j, rgb_c, disp_c, w_c, z_f)
+    if (C == 1) MN_CFZ(1); else if (C == 2) MN_CFZ(2); else if (C == 3) MN_CFZ(3); else if (C == 4) MN_CFZ(4);
+    else if (C <= 8) MN_CFZ(8); else MN_CFZ(16);
+#undef MN_CFZ
+    MN_LAUNCH_CHECK("composite_fine_z_kernel");
     return MI_NERF_OK;
 }
 

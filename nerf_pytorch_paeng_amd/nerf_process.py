@@ -158,13 +158,18 @@ def _render(rays: torch.Tensor, packed: PackedNeRF, opts, t_rand, u, seed: int, 
     dev = rays.device
     Sc, Nf = int(opts.N_samples_c), int(opts.N_samples_f)
     det = _det(opts)
-    cfg = ops.render_cfg(float(opts.near), float(opts.far), Sc, Nf, det, bf16)
-    if t_rand is None:
-        t_rand = ops.fill_uniform(seed, 0, ray_offset, n, Sc, dev)
-    else:
+    # jitter: explicit tensors when the caller injects them (or wants them back); otherwise the kernels draw it themselves from the
+    # same counter-based generator, keyed on (seed, ray_offset + ray, sample) -- identical values, no tensors, no extra launches
+    cfg = ops.render_cfg(float(opts.near), float(opts.far), Sc, Nf, det, bf16, seed=seed, ray_offset=ray_offset)
+    if t_rand is not None:
         t_rand = as_f32_dev(t_rand, dev)
+    elif intermediates:
+        t_rand = ops.fill_uniform(seed, 0, ray_offset, n, Sc, dev)
     if Nf > 0 and not det:
-        u = ops.fill_uniform(seed, 1, ray_offset, n, Nf, dev) if u is None else as_f32_dev(u, dev)
+        if u is not None:
+            u = as_f32_dev(u, dev)
+        elif intermediates:
+            u = ops.fill_uniform(seed, 1, ray_offset, n, Nf, dev)
     else:
         u = None
     blobs = packed.bf16() if bf16 else (packed.coarse, packed.fine)

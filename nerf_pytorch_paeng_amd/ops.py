@@ -210,15 +210,18 @@ def mlp_embedded(net: Net, packed: torch.Tensor, x: torch.Tensor) -> torch.Tenso
     return out
 
 
-def mlp_rays(net: Net, packed: torch.Tensor, rays: torch.Tensor, z: torch.Tensor, bf16: bool = False) -> torch.Tensor:
+def mlp_rays(net: Net, packed: torch.Tensor, rays: torch.Tensor, z: torch.Tensor, bf16: bool = False, points_per_wave: int = 0) -> torch.Tensor:
+    """Fused encoding + MLP over rays x depths.  ``points_per_wave`` (bf16 only): 0 = launch shape chosen per launch, 64 / 32 pinned."""
     n, S = z.shape
     if tuple(rays.shape) != (n, 6):
         raise MiNerfError(f"rays must be [n,6], got {tuple(rays.shape)}")
     raw = torch.empty(n, S, 4, dtype=torch.float32, device=z.device)
-    fn = lib().mi_nerf_mlp_rays_bf16 if bf16 else lib().mi_nerf_mlp_rays
+    args = (C.byref(net), dev_ptr(packed, "packed", torch.uint8, 16), dev_ptr(rays, "rays"), dev_ptr(z, "z"), n, S, dev_ptr(raw, "raw", align=16))
     with _guard(z.device):
-        check(fn(C.byref(net), dev_ptr(packed, "packed", torch.uint8, 16), dev_ptr(rays, "rays"), dev_ptr(z, "z"), n, S,
-                 dev_ptr(raw, "raw", align=16), stream_ptr(z.device)), "mi_nerf_mlp_rays")
+        if bf16:
+            check(lib().mi_nerf_mlp_rays_bf16_shape(*args, int(points_per_wave), stream_ptr(z.device)), "mi_nerf_mlp_rays_bf16_shape")
+        else:
+            check(lib().mi_nerf_mlp_rays(*args, stream_ptr(z.device)), "mi_nerf_mlp_rays")
     return raw
 
 
@@ -514,8 +517,15 @@ def permute_rows(src: torch.Tensor, perm: torch.Tensor) -> torch.Tensor:
 # ------------------------------------------------------------------------------------------------
 # fused render
 # ------------------------------------------------------------------------------------------------
-def render_cfg(near: float, far: float, Sc: int, Nf: int, det: bool, bf16: bool = False) -> RenderCfg:
-    return RenderCfg(float(near), float(far), int(Sc), int(Nf), int(bool(det)), int(bool(bf16)))
+BF16_SHAPES = {0: 1, 64: 2, 32: 3, 832: 4}          # points per wave (832: 8 waves of 32 per workgroup) -> mi_nerf_render_cfg.use_bf16
+
+
+def render_cfg(near: float, far: float, Sc: int, Nf: int, det: bool, bf16: bool = False, points_per_wave: int = 0, seed: int = 0,
+               ray_offset: int = 0) -> RenderCfg:
+    """``points_per_wave`` (bf16 only): 0 = the bf16 kernel's launch shape is chosen per launch; 64 / 32 pin it.
+    ``seed`` / ``ray_offset`` key the jitter the kernels draw themselves when render_rays gets no ``t_rand`` / ``u`` tensor."""
+    return RenderCfg(float(near), float(far), int(Sc), int(Nf), int(bool(det)), BF16_SHAPES[int(points_per_wave)] if bf16 else 0,
+                     int(seed) & 0xFFFFFFFF, 0, int(ray_offset))
 
 
 def workspace_layout(cfg: RenderCfg, n: int) -> WorkspaceLayout:
@@ -525,14 +535,15 @@ def workspace_layout(cfg: RenderCfg, n: int) -> WorkspaceLayout:
 
 
 def render_rays(net: Net, packed_c: torch.Tensor, packed_f: Optional[torch.Tensor], cfg: RenderCfg, rays: torch.Tensor,
-                t_rand: torch.Tensor, u: Optional[torch.Tensor], workspace: Optional[torch.Tensor] = None,
+                t_rand: Optional[torch.Tensor], u: Optional[torch.Tensor], workspace: Optional[torch.Tensor] = None,
                 out: Optional[Sequence[torch.Tensor]] = None):
-    """One mi_nerf_render_rays call.  Returns (rgb_c, disp_c, rgb_f|None, disp_f|None, workspace)."""
+    """One mi_nerf_render_rays call.  Returns (rgb_c, disp_c, rgb_f|None, disp_f|None, workspace).
+    ``t_rand`` / ``u`` None: the kernels draw the jitter themselves from (cfg.seed, cfg.ray_offset + ray, sample)."""
     n = rays.shape[0]
     dev = rays.device
-    if tuple(rays.shape) != (n, 6) or tuple(t_rand.shape) != (n, cfg.Sc):
-        raise MiNerfError(f"rays [n,6] / t_rand [n,{cfg.Sc}] expected, got {tuple(rays.shape)} / {tuple(t_rand.shape)}")
-    if cfg.Nf > 0 and not cfg.det and (u is None or tuple(u.shape) != (n, cfg.Nf)):
+    if tuple(rays.shape) != (n, 6) or (t_rand is not None and tuple(t_rand.shape) != (n, cfg.Sc)):
+        raise MiNerfError(f"rays [n,6] / t_rand [n,{cfg.Sc}] expected, got {tuple(rays.shape)} / {None if t_rand is None else tuple(t_rand.shape)}")
+    if cfg.Nf > 0 and not cfg.det and u is not None and tuple(u.shape) != (n, cfg.Nf):
         raise MiNerfError(f"u [n,{cfg.Nf}] expected")
     wl = workspace_layout(cfg, n)
     if workspace is None or workspace.numel() < wl.total:
@@ -567,13 +578,15 @@ def workspace_views(cfg: RenderCfg, n: int, workspace: torch.Tensor) -> Dict[str
     return v
 
 
-def time_mlp_rays(net: Net, packed: torch.Tensor, rays: torch.Tensor, z: torch.Tensor, raw: torch.Tensor, iters: int, bf16: bool = False) -> float:
+def time_mlp_rays(net: Net, packed: torch.Tensor, rays: torch.Tensor, z: torch.Tensor, raw: torch.Tensor, iters: int, bf16: bool = False,
+                  points_per_wave: int = 0) -> float:
     """Average device milliseconds per fused-MLP launch, from hipEvents on the launch stream."""
     n, S = z.shape
     ms = C.c_float(0.0)
     with _guard(z.device):
         check(lib().mi_nerf_time_mlp_rays(C.byref(net), dev_ptr(packed, "packed", torch.uint8, 16), dev_ptr(rays, "rays"), dev_ptr(z, "z"), n, S,
-                                          dev_ptr(raw, "raw", align=16), iters, int(bf16), C.byref(ms), stream_ptr(z.device)), "mi_nerf_time_mlp_rays")
+                                          dev_ptr(raw, "raw", align=16), iters, BF16_SHAPES[int(points_per_wave)] if bf16 else 0, C.byref(ms),
+                                          stream_ptr(z.device)), "mi_nerf_time_mlp_rays")
     return float(ms.value)
 
 

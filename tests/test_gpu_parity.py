@@ -576,19 +576,66 @@ def test_bf16_through_module_model(lego_rays):
 def test_bf16_mlp_vs_bf16_oracle(packed_big, lego_rays):
     """The bf16 kernel against the oracle with the kernel's rounding points (R.mlp_forward_bf16: bf16 weights, bf16 gamma(x), bf16
     activations, fp32 accumulation) -- the check that a systematic packing / ordering error cannot pass: such an error moves
-    outputs by O(1e-1) of their scale, fp32 summation order and round-to-bf16 boundary flips move them by O(1e-3)."""
+    outputs by O(1e-1) of their scale, fp32 summation order and round-to-bf16 boundary flips move them by O(1e-3).  Both launch
+    shapes (64 and 32 points per wave; the second serves small launches such as a 512-ray shard) and the launcher's own choice."""
     sd = synthetic.make_state_dict(0, 8, 256)
-    for n, S in ((64, 192), (33, 100), (5, 64)):
+    for n, S in ((64, 192), (33, 100), (5, 64), (512, 64), (512, 192)):
         rays = lego_rays[:n].contiguous()
         z = torch.sort(T(R.counter_uniform(2, 0, 0, n, S)) * 4 + 2, -1)[0]
-        raw16 = ops.mlp_rays(packed_big.net, packed_big.bf16()[1], rays, z.to(DEV), bf16=True).cpu()
         ref = R.mlp_forward_bf16(sd, "model_fine.", R.embed(rays.cpu(), z, 10, 4), 8, 63, 27).reshape(n, S, 4)
-        e = (raw16 - ref).abs()
-        rel = [float(e[..., c].mean() / ref[..., c].abs().mean()) for c in range(4)]
-        print(f"bf16 kernel vs bf16 oracle n={n} S={S}: mean |err| / mean |ref| per channel {[f'{v:.1e}' for v in rel]}, max |err| {float(e.max()):.3e}")
-        assert torch.isfinite(raw16).all()
-        assert max(rel) < 2e-3, rel                      # observed 2e-4 .. 5e-4
-        assert float(e.max()) < 0.2, float(e.max())      # a flipped bf16 rounding of one activation, amplified by the x20 density head
+        outs = {}
+        for ppw in (64, 32, 0):
+            raw16 = ops.mlp_rays(packed_big.net, packed_big.bf16()[1], rays, z.to(DEV), bf16=True, points_per_wave=ppw).cpu()
+            outs[ppw] = raw16
+            e = (raw16 - ref).abs()
+            rel = [float(e[..., c].mean() / ref[..., c].abs().mean()) for c in range(4)]
+            print(f"bf16 kernel ({ppw or 'auto'} points per wave) vs bf16 oracle n={n} S={S}: mean |err| / mean |ref| per channel "
+                  f"{[f'{v:.1e}' for v in rel]}, max |err| {float(e.max()):.3e}")
+            assert torch.isfinite(raw16).all()
+            assert max(rel) < 2e-3, rel                      # observed 2e-4 .. 8e-4
+            assert float(e.max()) < 0.2, float(e.max())      # a flipped bf16 rounding of one activation, amplified by the x20 density head
+        # a point's arithmetic does not depend on the shape of the launch that carries it
+        assert torch.equal(outs[64], outs[32]) and torch.equal(outs[0], outs[64])
+
+
+@pytest.mark.parametrize("n,S", [(341, 192), (342, 192), (700, 192), (1366, 192), (1500, 192), (2731, 192), (4096, 192), (1000, 100), (3000, 33), (171, 192)])
+def test_bf16_launch_plans_agree(n, S, packed_big, lego_rays):
+    """The launcher's plan (whole rounds of the 64-point shape + the remainder as one round of the 32-point shape, split at a TILE, not
+    a ray, boundary; ray-major or flat tile walk) against each shape pinned over the whole call: every point of every ray written,
+    bit-identical.  Sizes straddle the round boundaries of a 256-CU chip (341.33 rays x 192 samples = one 64-point round)."""
+    rays = lego_rays[:n].contiguous()
+    z = torch.sort(T(R.counter_uniform(6, 0, 0, n, S)) * 4 + 2, -1)[0].to(DEV)
+    outs = []
+    for ppw in (64, 32, 0):
+        raw = torch.full((n, S, 4), float("nan"), device=DEV)
+        args = (__import__("ctypes").byref(packed_big.net), packed_big.bf16()[1].data_ptr(), rays.data_ptr(), z.data_ptr(), n, S, raw.data_ptr(), ppw,
+                torch.cuda.current_stream(DEV).cuda_stream)
+        from nerf_pytorch_paeng_amd._lib import check, lib
+        check(lib().mi_nerf_mlp_rays_bf16_shape(*args), "mi_nerf_mlp_rays_bf16_shape")
+        assert torch.isfinite(raw).all(), (n, S, ppw)          # no point left unwritten by a split launch
+        outs.append(raw)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+def test_bf16_small_launch_shape_whole_step(packed_big, lego_rays):
+    """A 512-ray shard (what one of 8 GPUs renders of BASELINE config #5's batch) through render_rays with the launch shape chosen
+    by the launcher, pinned to 64 and pinned to 32 points per wave: identical outputs; PSNR against the fp32 path as for 4096 rays."""
+    opts = make_opts()
+    rays = lego_rays[:512].contiguous()
+    a = NP.render_rays(rays, packed_big, None, opts, seed=3, return_intermediates=True)
+    blobs = packed_big.bf16()
+    outs = {}
+    for ppw in (0, 64, 32):
+        cfg = ops.render_cfg(opts.near, opts.far, 64, 128, False, True, points_per_wave=ppw)
+        outs[ppw] = ops.render_rays(packed_big.net, blobs[0], blobs[1], cfg, rays, a["_t_rand"], a["_u"])[:4]
+    for ppw in (64, 32):
+        for x, y in zip(outs[0], outs[ppw]):
+            assert torch.equal(x, y), ppw
+    for k, got in (("rgb_c", outs[0][0]), ("rgb_f", outs[0][2])):
+        mse = float(((a[k] - got) ** 2).mean())
+        print(f"bf16 (512-ray shard) vs fp32 {k}: PSNR {R.mse2psnr(mse):.1f} dB")
+        assert torch.isfinite(got).all() and R.mse2psnr(mse) > (70.0 if k == "rgb_c" else 50.0), (k, R.mse2psnr(mse))
+    assert torch.equal(NP.render_rays(rays, packed_big, None, opts, t_rand=a["_t_rand"], u=a["_u"], bf16=True)["rgb_f"], outs[0][2])
 
 
 @pytest.mark.parametrize("D,skip", [(7, 5), (3, -1), (8, 3), (2, -1), (6, 4), (9, 0)])
@@ -605,7 +652,8 @@ def test_bf16_other_depths_and_skip_positions(D, skip, lego_rays):
     n, S = 37, 96
     rays = lego_rays[:n].contiguous()
     z = torch.sort(T(R.counter_uniform(4, 0, 0, n, S)) * 4 + 2, -1)[0]
-    raw16 = ops.mlp_rays(packed.net, packed.bf16()[1], rays, z.to(DEV), bf16=True).cpu()
+    raw16 = ops.mlp_rays(packed.net, packed.bf16()[1], rays, z.to(DEV), bf16=True, points_per_wave=64).cpu()
+    assert torch.equal(raw16, ops.mlp_rays(packed.net, packed.bf16()[1], rays, z.to(DEV), bf16=True, points_per_wave=32).cpu())
     ref = R.mlp_forward_bf16(sd, "model_fine.", R.embed(rays.cpu(), z, 10, 4), D, 63, 27, skips=skips).reshape(n, S, 4)
     e = (raw16 - ref).abs()
     rel = [float(e[..., c].mean() / ref[..., c].abs().mean()) for c in range(4)]
@@ -616,6 +664,34 @@ def test_bf16_other_depths_and_skip_positions(D, skip, lego_rays):
     raw32 = ops.mlp_rays(packed.net, packed.fine, rays, z.to(DEV)).cpu()
     ref32 = R.mlp_forward(sd, "model_fine.", R.embed(rays.cpu(), z, 10, 4).double(), D, 63, 27, skips=skips, dtype=torch.float64).reshape(n, S, 4)
     assert err(raw32, ref32) <= 2e-4, err(raw32, ref32)
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_in_kernel_jitter_equals_explicit_tensors(bf16, packed_big, lego_rays):
+    """render_rays draws its jitter inside the sampling kernels when no t_rand / u tensor is passed (the reference draws torch.rand
+    inside pre_process / sample_pdf, nerf_process.py:58-60,162-163): the same counter-based values mi_nerf_fill_uniform writes, keyed
+    on (seed, ray_offset + ray, sample) -- so outputs are bit-identical to the explicit-tensor call, for any shard of the batch.
+    Also: the fused composite + resample + merge launch of the fused entry equals the staged kernels bit for bit."""
+    opts = make_opts()
+    n, first = 700, 1234
+    rays = lego_rays[first:first + n].contiguous()
+    a = NP.render_rays(rays, packed_big, None, opts, seed=9, ray_offset=first, bf16=bf16)
+    t_rand, u = ops.fill_uniform(9, 0, first, n, 64, DEV), ops.fill_uniform(9, 1, first, n, 128, DEV)
+    b = NP.render_rays(rays, packed_big, None, opts, t_rand=t_rand, u=u, bf16=bf16, return_intermediates=True)
+    c = NP.render_rays(rays, packed_big, None, opts, seed=9, ray_offset=first, bf16=bf16, return_intermediates=True)
+    for k in ("rgb_c", "disp_c", "rgb_f", "disp_f"):
+        assert torch.equal(a[k], b[k]) and torch.equal(a[k], c[k]), k
+    assert torch.equal(c["_t_rand"], t_rand) and torch.equal(c["_u"], u)
+    # staged: composite and fine_z as their own launches on the fused call's coarse outputs
+    rgb_c, disp_c, _, w_c, _ = ops.composite(b["_raw_c"], b["_z_c"], rays)
+    assert torch.equal(rgb_c, b["rgb_c"]) and torch.equal(disp_c, b["disp_c"]) and torch.equal(w_c, b["_weights_c"])
+    assert torch.equal(ops.fine_z(b["_z_c"], w_c, 128, False, u), b["_z_f"])
+    assert torch.equal(ops.stratified_z(opts.near, opts.far, t_rand), b["_z_c"])
+    # deterministic sampling ignores u; coarse-only skips the resampling
+    d0 = NP.render_rays(rays, packed_big, None, make_opts(perturb=0.0), seed=9, ray_offset=first, bf16=bf16, return_intermediates=True)
+    assert d0["_u"] is None and torch.equal(ops.fine_z(d0["_z_c"], d0["_weights_c"], 128, True, None), d0["_z_f"])
+    e0 = NP.render_rays(rays, packed_big, None, make_opts(N_samples_f=0), seed=9, ray_offset=first, bf16=bf16)
+    assert "rgb_f" not in e0 and torch.equal(e0["rgb_c"], a["rgb_c"])
 
 
 def test_config2_all_rays_vs_oracle(packed_big, lego_rays):

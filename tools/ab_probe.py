@@ -1,6 +1,6 @@
 """A/B timing of the fused MLP kernel: the shipped library against a variant built with
 `python -m nerf_pytorch_paeng_amd.build --variant TAG -D...`, alternating in ONE process on ONE box (box-to-box
-variance is ~0.5 %, more than most single changes):  python tools/ab_probe.py TAG[,TAG2,...] [rounds] [bf16]"""
+variance is ~0.5 %, more than most single changes):  python tools/ab_probe.py TAG[,TAG2,...] [rounds] [bf16] [points_per_wave] [rays] [S]"""
 import ctypes as C
 import os
 import sys
@@ -13,14 +13,18 @@ from nerf_pytorch_paeng_amd import _lib, ops, synthetic, weights
 tag = sys.argv[1]
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 bf16 = len(sys.argv) > 3 and sys.argv[3] == "bf16"
+ppw = int(sys.argv[4]) if len(sys.argv) > 4 else 0           # bf16 launch shape: 0 = the launcher's choice, 64 / 32 pinned
+N = int(sys.argv[5]) if len(sys.argv) > 5 else 4096
+S = int(sys.argv[6]) if len(sys.argv) > 6 else 192
+use_bf16 = {0: 1, 64: 2, 32: 3}[ppw] if bf16 else 0
 dev = torch.device("cuda:0")
 packed = weights.PackedNeRF.from_state_dict(synthetic.make_state_dict(0, 8, 256), dev)
 K, H, W = synthetic.lego_camera()
-pix = torch.from_numpy(synthetic.pixel_batch(H, W, 4096, 0)).to(dev)
+pix = torch.from_numpy(synthetic.pixel_batch(H, W, N, 0)).to(dev)
 o, d = ops.make_o_d_pixels(W, H, K, synthetic.pose_spherical(0.0, -30.0, 4.0), pix)
 rays = torch.cat([o, d], -1).contiguous()
-z = torch.sort(torch.rand(4096, 192, device=dev) * 4 + 2, -1)[0]
-raw = torch.empty(4096, 192, 4, device=dev)
+z = torch.sort(torch.rand(N, S, device=dev) * 4 + 2, -1)[0]
+raw = torch.empty(N, S, 4, device=dev)
 
 libs = {"shipped": _lib.lib()}
 for tg in tag.split(","):
@@ -34,7 +38,7 @@ for tg in tag.split(","):
 def time(lib, iters=20):
     ms = C.c_float(0.0)
     blob = packed.bf16()[1] if bf16 else packed.fine
-    rc = lib.mi_nerf_time_mlp_rays(C.byref(packed.net), blob.data_ptr(), rays.data_ptr(), z.data_ptr(), 4096, 192, raw.data_ptr(), iters, int(bf16),
+    rc = lib.mi_nerf_time_mlp_rays(C.byref(packed.net), blob.data_ptr(), rays.data_ptr(), z.data_ptr(), N, S, raw.data_ptr(), iters, use_bf16,
                                    C.byref(ms), torch.cuda.current_stream(dev).cuda_stream)
     assert rc == 0
     return ms.value
@@ -47,4 +51,5 @@ for _ in range(rounds):
     for k, lib in libs.items():
         res[k].append(time(lib))
 for k, v in res.items():
-    print(f"{k:10s} fine-net launch: min {min(v):.4f} ms  median {sorted(v)[len(v) // 2]:.4f} ms   {[round(x, 4) for x in v]}")
+    shape = f", {ppw or 'auto'} pts/wave" if bf16 else ""
+    print(f"{k:10s} {N} x {S} launch{shape}: min {min(v):.4f} ms  median {sorted(v)[len(v) // 2]:.4f} ms   {[round(x, 4) for x in v]}")
