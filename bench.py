@@ -337,8 +337,8 @@ def worker(args) -> None:
         legs = []
         for n in (256, 512, 1024, 2048):
             b = make_batch(0, n)
-            reps = max(args.steps, 20)
-            for _ in range(3):
+            reps = max(args.steps, 50)
+            for _ in range(10):                      # a 100 us step: give the clock governor a few ms before timing
                 step_fn(b)
             torch.cuda.synchronize(dev)
             t0 = time.perf_counter()

@@ -45,7 +45,20 @@ for n in rays_list:
                 ops.render_rays(packed.net, blobs[0], blobs[1], cfgs[s], rays, t_rand, u, workspace=ws, out=out)
             torch.cuda.synchronize()
             res[s]["step"].append(1e3 * (time.perf_counter() - t0) / reps)
+    # the launcher's own plan with the jitter drawn inside the sampling kernels (what bench.py's step does)
+    own = []
+    for _ in range(ROUNDS):
+        for _ in range(5):
+            ops.render_rays(packed.net, blobs[0], blobs[1], cfgs[0], rays, None, None, workspace=ws, out=out)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(40):
+            ops.render_rays(packed.net, blobs[0], blobs[1], cfgs[0], rays, None, None, workspace=ws, out=out)
+        torch.cuda.synchronize()
+        own.append(1e3 * (time.perf_counter() - t0) / 40)
     for s in SHAPES:
         c, f, st = (float(np.median(res[s][k])) for k in ("coarse", "fine", "step"))
         print(f"{n:5d} rays  {({0: 'auto', 832: '8x32'}.get(s, s))!s:>4} pts/wave: coarse launch {1e3 * c:7.1f} us  fine launch {1e3 * f:7.1f} us  step {1e3 * st:7.1f} us"
               f"  = {n / st * 1e3 / 1e6:6.3f} M rays/s", flush=True)
+    st = float(np.median(own))
+    print(f"{n:5d} rays  auto, jitter drawn in the kernels: step {1e3 * st:7.1f} us  = {n / st * 1e3 / 1e6:6.3f} M rays/s", flush=True)
