@@ -425,14 +425,22 @@ def worker(args) -> None:
                  "peak_mem_GiB": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
                  "what": "batchify_rays_and_render_by_chunk (grad) + MSE(rgb_c)+MSE(rgb_f) + loss.backward() + Adam.step(), "
                          f"{N_RAYS} rays per GPU, each rank an independent replica (the reference has no data-parallel training)"}
-        # roofline leg of the training kernels' GEMM: one 256x256 weight-gradient product over the fine net's 786 432 points
-        dlt = torch.randn(N_RAYS * (SC + NF) + 64, 256, device=dev)
-        xin = torch.randn(N_RAYS * (SC + NF) + 64, 256, device=dev)
-        ops.wgrad_product(dlt, 256, xin, 256, N_RAYS * (SC + NF), iters=2)
-        _, _, wg_ms = ops.wgrad_product(dlt, 256, xin, 256, N_RAYS * (SC + NF), iters=10, timed=True)
-        wg_tf = 2.0 * 256 * 256 * N_RAYS * (SC + NF) / (wg_ms * 1e-3) / 1e12
+        # roofline leg of the training kernels' GEMM: the 256x256 weight-gradient products over the fine net's 786 432 points, as the
+        # backward pass runs them (nine in one launch: mi_nerf_wgrad_products), and one product launched on its own
+        n_pts = N_RAYS * (SC + NF)
+        dlt = torch.randn(n_pts + 64, 256, device=dev)
+        xin = torch.randn(n_pts + 64, 256, device=dev)
+        ops.wgrad_product(dlt, 256, xin, 256, n_pts, iters=2)
+        _, _, wg_ms = ops.wgrad_product(dlt, 256, xin, 256, n_pts, iters=10, timed=True)
+        wg_tf = 2.0 * 256 * 256 * n_pts / (wg_ms * 1e-3) / 1e12
+        ops.wgrad_products([dlt] * 9, [xin] * 9, n_pts, iters=1)
+        _, _, wg9_ms = ops.wgrad_products([dlt] * 9, [xin] * 9, n_pts, iters=5, timed=True)
+        wg9_tf = 9 * 2.0 * 256 * 256 * n_pts / (wg9_ms * 1e-3) / 1e12
         train["wgrad_256x256"] = {"ms": round(wg_ms, 4), "achieved_TFLOPs": round(wg_tf, 1), "frac_of_f32_mfma_peak": round(wg_tf / PEAK_F32_MFMA_TFLOPS, 4),
-                                  "what": "wgrad_big_kernel + reduce_partial_kernel, hipEvents on the launch stream"}
+                                  "what": "ONE product on its own (mi_nerf_wgrad_product): wgrad_big_kernel over 256 point slices + reduce, hipEvents on the launch stream"}
+        train["wgrad_9x256x256"] = {"ms": round(wg9_ms, 4), "ms_per_product": round(wg9_ms / 9, 4), "achieved_TFLOPs": round(wg9_tf, 1),
+                                    "frac_of_f32_mfma_peak": round(wg9_tf / PEAK_F32_MFMA_TFLOPS, 4),
+                                    "what": "nine products in one launch (mi_nerf_wgrad_products), the form the backward pass uses for a net's wide layers"}
         del model, optim, dlt, xin
         torch.cuda.empty_cache()
 

@@ -244,6 +244,14 @@ size_t mi_nerf_wgrad_scratch_bytes(void);
 int mi_nerf_wgrad_product(const float* delta_dev, int ldd, int M, const float* x_dev, int ldx, int N, int64_t P, float* out_dev,
                           int ldo, float* bias_dev, void* scratch_dev, size_t scratch_bytes, int iters, float* avg_ms_out,
                           void* stream);
+/* n (1..12) such products over the SAME P points in ONE launch, both sides wider than 64 columns (at most 256): the form the
+ * backward pass itself uses for the nine 256 x 256 products of an 8 x 256 network.  The CUs are shared out between the products,
+ * so each is cut into (CUs / n) point slices and writes / reduces 1 / n of the partial sums a stand-alone launch does (a lone
+ * 256 x 256 product over 786 432 points: 0.74 of the fp32 MFMA peak; nine in one launch: 0.91).  Arrays of n HOST entries
+ * (device pointers, pitches, sizes); bias_dev may be NULL, or hold NULL entries. */
+int mi_nerf_wgrad_products(int n, const float* const* delta_dev, const int* ldd, const int* M, const float* const* x_dev, const int* ldx,
+                           const int* N, int64_t P, float* const* out_dev, const int* ldo, float* const* bias_dev, void* scratch_dev,
+                           size_t scratch_bytes, int iters, float* avg_ms_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Either side of the path in the reference's callers.  HBM-bound streaming ops.

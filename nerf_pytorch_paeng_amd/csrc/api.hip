@@ -54,6 +54,8 @@ int mlp_embedded_fp32(const mi_nerf_net*, const void*, const float*, int64_t, fl
 int mlp_rays_bf16(const mi_nerf_net*, const void*, const float*, const float*, int64_t, int, float*, hipStream_t, int points_per_wave);
 // use_bf16 of mi_nerf_render_cfg / mi_nerf_time_mlp_rays -> launch shape of the bf16 kernel (0: chosen per launch)
 static inline int bf16_points_per_wave(int use_bf16) { return use_bf16 == 2 ? 64 : (use_bf16 == 3 ? 32 : (use_bf16 == 4 ? 832 : 0)); }
+int wgrad_products(int, const float* const*, const int*, const int*, const float* const*, const int*, const int*, int64_t, float* const*, const int*,
+                   float* const*, void*, size_t, hipStream_t);
 int mlp_rays_fp32_stash(const mi_nerf_net*, const void*, const float*, const float*, int64_t, int, float*, float*, float*, float*, unsigned*,
                         unsigned*, hipStream_t);
 int mlp_backward_fp32(const mi_nerf_net*, const void*, const void*, const float*, const float*, int64_t, int, const float*, const void*, void*,
@@ -383,9 +385,9 @@ int mi_nerf_time_mlp_rays(const mi_nerf_net* net, const void* packed, const floa
 }
 
 size_t mi_nerf_wgrad_scratch_bytes(void) { return wgrad_scratch_bytes(); }
-int mi_nerf_wgrad_product(const float* delta, int ldd, int M, const float* x, int ldx, int N, int64_t P, float* out, int ldo, float* bias,
-                          void* scratch, size_t scratch_bytes, int iters, float* avg_ms, void* stream) {
-    hipStream_t st = (hipStream_t)stream;
+// launches `body()` iters times on `st`; *avg_ms (optional) = average device time by hipEvents on that stream
+extern "C++" template <typename F>
+static int timed_launches(int iters, float* avg_ms, hipStream_t st, F body) {
     MN_CHECK_ARG(iters >= 1, "bad iters");
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (avg_ms) {
@@ -394,7 +396,7 @@ int mi_nerf_wgrad_product(const float* delta, int ldd, int M, const float* x, in
         MN_HIP(hipEventRecord(e0, st));
     }
     int rc = MI_NERF_OK;
-    for (int i = 0; i < iters && rc == MI_NERF_OK; ++i) rc = wgrad_product(delta, ldd, M, x, ldx, N, P, out, ldo, bias, scratch, scratch_bytes, st);
+    for (int i = 0; i < iters && rc == MI_NERF_OK; ++i) rc = body();
     if (avg_ms) {
         MN_HIP(hipEventRecord(e1, st));
         MN_HIP(hipEventSynchronize(e1));
@@ -405,6 +407,17 @@ int mi_nerf_wgrad_product(const float* delta, int ldd, int M, const float* x, in
         *avg_ms = ms / (float)iters;
     }
     return rc;
+}
+int mi_nerf_wgrad_product(const float* delta, int ldd, int M, const float* x, int ldx, int N, int64_t P, float* out, int ldo, float* bias,
+                          void* scratch, size_t scratch_bytes, int iters, float* avg_ms, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    return timed_launches(iters, avg_ms, st, [&] { return wgrad_product(delta, ldd, M, x, ldx, N, P, out, ldo, bias, scratch, scratch_bytes, st); });
+}
+int mi_nerf_wgrad_products(int n, const float* const* delta, const int* ldd, const int* M, const float* const* x, const int* ldx, const int* N,
+                           int64_t P, float* const* out, const int* ldo, float* const* bias, void* scratch, size_t scratch_bytes, int iters,
+                           float* avg_ms, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    return timed_launches(iters, avg_ms, st, [&] { return wgrad_products(n, delta, ldd, M, x, ldx, N, P, out, ldo, bias, scratch, scratch_bytes, st); });
 }
 
 int mi_nerf_selftest_mfma(void* stream) {

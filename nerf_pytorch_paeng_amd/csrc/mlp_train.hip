@@ -329,24 +329,30 @@ void wgrad_big_kernel(const WgradArgs a) {
     else if (wn == 0) loop(std::integral_constant<int, 0>{});
     else loop(std::integral_constant<int, 1>{});
     // D[i'][j]: i' = (r&3) + 8*(r>>2) + 4*kh is the A-side lane index, j = lane & 31 the B-side one
+    // The lane index is taken afresh (mbcnt) for the read-out: every VGPR is spoken for inside the loop, and a lane-derived value kept
+    // alive across it for these few lines was the kernel's one spilled register.
+    const int lane_o = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int i_o = lane_o & 31, kh_o = lane_o >> 5;
     float* out = a.partial + ((size_t)b * a.slices + slice) * (256 * 256);
 #pragma unroll
     for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int m = m0 + 4 * ((r & 3) + 8 * (r >> 2) + 4 * kh) + tm;
-            f32x4 v; v[0] = acc[tm][0][r]; v[1] = acc[tm][1][r]; v[2] = acc[tm][2][r]; v[3] = acc[tm][3][r];
-            *(f32x4*)(out + (size_t)m * 256 + n0 + 4 * i) = v;
+            const int m = m0 + 4 * ((r & 3) + 8 * (r >> 2) + 4 * kh_o) + tm;
+            f32x4 v;                                             // explicit just-in-time reads out of the AGPR file (see wgrad_narrow_kernel)
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v[tn]) : "a"(acc[tm][tn][r]));
+            *(f32x4*)(out + (size_t)m * 256 + n0 + 4 * i_o) = v;
         }
     if (want_bias) {                                             // uniform over the workgroup
-        if (wn == 1) bshare[wm][lane] = bsum;                    // odd k-steps of the same columns
+        if (wn == 1) bshare[wm][lane_o] = bsum;                    // odd k-steps of the same columns
         __syncthreads();
         if (wn == 0) {
-            bsum += bshare[wm][lane];
+            bsum += bshare[wm][lane_o];
             f32x4 sv;
 #pragma unroll
             for (int e = 0; e < 4; ++e) sv[e] = bsum[e] + __shfl_xor(bsum[e], 32, 64);      // even + odd points of every k-step
-            if (kh == 0) *(f32x4*)(a.bpartial + ((size_t)b * a.slices + slice) * 256 + m0 + 4 * i) = sv;
+            if (kh_o == 0) *(f32x4*)(a.bpartial + ((size_t)b * a.slices + slice) * 256 + m0 + 4 * i_o) = sv;
         }
     }
 }
@@ -464,22 +470,32 @@ void wgrad_narrow_kernel(const NarrowArgs a) {
     // D[i'][j]: i' = (r&3) + 8*(r>>2) + 4*kh <-> wide column 128*(tm>>2) + 4*i' + (tm&3);  j = lane & 31 <-> narrow column 32*tn + j
     constexpr int Wp = 128 * WQ, Np = 32 * NN;
     __shared__ float red[3][16][64];
-    float* out = a.partial + (size_t)blockIdx.x * Wp * Np;
+    // The partial is written through a buffer descriptor: ONE per-lane offset (the lane's part of the element index: 16 kh rows + column
+    // i) plus a compile-time scalar offset per (tile, register).  With plain 64-bit addressing hipcc materialised the 256 store
+    // addresses of the unrolled read-out as VGPR pairs and spilled accumulators around them (the <2,2> instantiations: 64-100 bytes
+    // of scratch, none of it in the loop).
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void*)(a.partial + (size_t)blockIdx.x * Wp * Np), 0, Wp * Np * 4, 0x00020000);
+    const unsigned vout = (unsigned)((16 * kh * Np + i) * 4);
 #pragma unroll
     for (int tm = 0; tm < 4 * WQ; ++tm)
 #pragma unroll
         for (int tn = 0; tn < NN; ++tn) {
+            // the accumulators are read out of the AGPR file ONE TILE AT A TIME, by an explicit v_accvgpr_read: left to itself hipcc copies
+            // all 256 into VGPRs at the loop exit (they are VALU / LDS-store operands from here on) and spills what does not fit
+            float t[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(t[r]) : "a"(acc[tm][tn][r]));
             if (wave > 0) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) red[wave - 1][r][lane] = acc[tm][tn][r];
+                for (int r = 0; r < 16; ++r) red[wave - 1][r][lane] = t[r];
             }
             __syncthreads();
             if (wave == 0) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float v = ((acc[tm][tn][r] + red[0][r][lane]) + red[1][r][lane]) + red[2][r][lane];
-                    const int w = 128 * (tm >> 2) + 4 * ((r & 3) + 8 * (r >> 2) + 4 * kh) + (tm & 3);
-                    out[(size_t)w * Np + 32 * tn + i] = v;
+                    const float v = ((t[r] + red[0][r][lane]) + red[1][r][lane]) + red[2][r][lane];
+                    const int w0 = 128 * (tm >> 2) + 4 * ((r & 3) + 8 * (r >> 2)) + (tm & 3);      // + 16 kh: in the lane offset
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, vout, (w0 * Np + 32 * tn) * 4, 0);
                 }
             }
             __syncthreads();
@@ -715,6 +731,23 @@ static int run_wgrad(const float* dlt, int ldd, int M, const float* x, int ldx, 
 }
 
 size_t wgrad_scratch_bytes() { return WGRAD_PARTIAL_FLOATS * 4; }
+
+// n (<= 12) wide products over the SAME P points in one launch -- how the backward pass itself runs the nine 256 x 256 products of
+// a network (run_wgrad_batch): the CUs are shared out between the products, so a product is cut into num_cus / n point slices
+// and writes / reduces 1 / n of the partials a stand-alone launch does.
+int wgrad_products(int n, const float* const* dlt, const int* ldd, const int* M, const float* const* x, const int* ldx, const int* N, int64_t P,
+                   float* const* out, const int* ldo, float* const* bias, void* scratch, size_t scratch_bytes, hipStream_t st) {
+    MN_CHECK_ARG(n >= 1 && n <= WG_MAXB, "between 1 and %d products per launch (got %d)", WG_MAXB, n);
+    MN_CHECK_ARG(P >= 1 && dlt && ldd && M && x && ldx && N && out && ldo && scratch, "bad sizes / NULL pointer");
+    MN_CHECK_ARG(scratch_bytes >= WGRAD_PARTIAL_FLOATS * 4, "scratch too small: %zu < %zu", scratch_bytes, WGRAD_PARTIAL_FLOATS * 4);
+    WideProduct pr[WG_MAXB];
+    for (int b = 0; b < n; ++b) {
+        MN_CHECK_ARG(dlt[b] && x[b] && out[b] && M[b] > 64 && N[b] > 64 && ldd[b] >= M[b] && ldx[b] >= N[b] && ldo[b] >= N[b],
+                     "product %d: the batched entry takes wide products (more than 64 columns on both sides), M=%d N=%d", b, M[b], N[b]);
+        pr[b] = WideProduct{dlt[b], ldd[b], M[b], x[b], ldx[b], N[b], out[b], ldo[b], bias ? bias[b] : nullptr};
+    }
+    return run_wgrad_batch(pr, n, P, (float*)scratch, st);
+}
 
 // stand-alone product dW = delta^T x input (+ column sums of delta) for tests and the bench's roofline leg
 int wgrad_product(const float* dlt, int ldd, int M, const float* x, int ldx, int N, int64_t P, float* out, int ldo, float* bias, void* scratch,

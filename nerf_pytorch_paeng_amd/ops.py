@@ -359,8 +359,10 @@ def mlp_rays_train(net: Net, packed: torch.Tensor, rays: torch.Tensor, z: torch.
 
 
 def mlp_backward(net: Net, packed: torch.Tensor, packed_bwd: torch.Tensor, rays: torch.Tensor, z: torch.Tensor, d_raw: torch.Tensor,
-                 stash: torch.Tensor, work: Optional[torch.Tensor] = None, stage: int = 0):
-    """d_raw [n,S,4] -> flat parameter gradient (param_names order).  Returns (grads, work)."""
+                 stash: torch.Tensor, work: Optional[torch.Tensor] = None, stage: int = 0, grads: Optional[torch.Tensor] = None):
+    """d_raw [n,S,4] -> flat parameter gradient (param_names order).  Returns (grads, work).
+    The weight-gradient kernels write EVERY element of the flat vector (each parameter block is the output of exactly one product's
+    reduction), so it is allocated uninitialised; ``grads`` lets a test pass a poisoned buffer to check exactly that."""
     n, S = z.shape
     if tuple(d_raw.shape) != (n, S, 4) or tuple(rays.shape) != (n, 6):
         raise MiNerfError(f"d_raw must be {(n, S, 4)} and rays {(n, 6)}, got {tuple(d_raw.shape)} / {tuple(rays.shape)}")
@@ -368,7 +370,10 @@ def mlp_backward(net: Net, packed: torch.Tensor, packed_bwd: torch.Tensor, rays:
     dev = z.device
     if work is None:
         work = torch.empty(lay.work_bytes, dtype=torch.uint8, device=dev)
-    grads = torch.zeros(param_count(net), dtype=torch.float32, device=dev)
+    if grads is None:
+        grads = torch.empty(param_count(net), dtype=torch.float32, device=dev)
+    elif grads.numel() != param_count(net):
+        raise MiNerfError(f"grads must have {param_count(net)} elements, got {grads.numel()}")
     with _guard(dev):
         check(lib().mi_nerf_mlp_backward(C.byref(net), dev_ptr(packed, "packed", torch.uint8, 16), dev_ptr(packed_bwd, "packed_bwd", torch.uint8, 16),
                                          dev_ptr(rays, "rays"), dev_ptr(z, "z"), n, S, dev_ptr(d_raw, "d_raw", align=16),
@@ -391,15 +396,17 @@ def mlp_embedded_train(net: Net, packed: torch.Tensor, x: torch.Tensor):
     return out, stash
 
 
-def mlp_embedded_backward(net: Net, packed: torch.Tensor, packed_bwd: torch.Tensor, x: torch.Tensor, d_out: torch.Tensor, stash: torch.Tensor) -> torch.Tensor:
-    """d_out [n,4] -> flat parameter gradient (param_names order) for the embedded-row forward."""
+def mlp_embedded_backward(net: Net, packed: torch.Tensor, packed_bwd: torch.Tensor, x: torch.Tensor, d_out: torch.Tensor, stash: torch.Tensor,
+                          grads: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """d_out [n,4] -> flat parameter gradient (param_names order) for the embedded-row forward (every element written, see mlp_backward)."""
     n = x.shape[0]
     if tuple(d_out.shape) != (n, 4):
         raise MiNerfError(f"d_out must be {(n, 4)}, got {tuple(d_out.shape)}")
     lay = train_layout(net, (n + 31) // 32, 32)
     dev = x.device
     work = torch.empty(lay.work_bytes, dtype=torch.uint8, device=dev)
-    grads = torch.zeros(param_count(net), dtype=torch.float32, device=dev)
+    if grads is None:
+        grads = torch.empty(param_count(net), dtype=torch.float32, device=dev)
     with _guard(dev):
         check(lib().mi_nerf_mlp_embedded_backward(C.byref(net), dev_ptr(packed, "packed", torch.uint8, 16), dev_ptr(packed_bwd, "packed_bwd", torch.uint8, 16),
                                                   dev_ptr(x, "x"), n, dev_ptr(d_out, "d_out", align=16), dev_ptr(stash, "stash", torch.uint8, 16),
@@ -424,6 +431,34 @@ def wgrad_product(delta: torch.Tensor, M: int, x: torch.Tensor, N: int, P: int, 
                                           N, dev_ptr(bias), dev_ptr(scratch, "scratch", torch.uint8, 16), scratch.numel(), int(iters),
                                           C.byref(ms) if timed else None, stream_ptr(dev)), "mi_nerf_wgrad_product")
     return out, bias, (float(ms.value) if timed else None)
+
+
+def wgrad_products(deltas: Sequence[torch.Tensor], xs: Sequence[torch.Tensor], P: int, Ms: Optional[Sequence[int]] = None,
+                   Ns: Optional[Sequence[int]] = None, want_bias: bool = True, iters: int = 1, timed: bool = False):
+    """Several wide products over the same P points in ONE launch (mi_nerf_wgrad_products): out[b] = deltas[b][:P, :M_b]^T xs[b][:P, :N_b]
+    (+ bias[b] = column sums of deltas[b]).  This is how the backward pass runs a network's 256 x 256 products.  Returns
+    (outs, biases, avg_ms)."""
+    n = len(deltas)
+    if n == 0 or len(xs) != n:
+        raise MiNerfError("deltas / xs must be non-empty lists of equal length")
+    dev = deltas[0].device
+    Ms = [d.shape[1] for d in deltas] if Ms is None else list(Ms)
+    Ns = [x.shape[1] for x in xs] if Ns is None else list(Ns)
+    for d, x, M, N in zip(deltas, xs, Ms, Ns):
+        if d.dim() != 2 or x.dim() != 2 or d.shape[0] < P or x.shape[0] < P or d.shape[1] < M or x.shape[1] < N:
+            raise MiNerfError(f"operands {tuple(d.shape)} / {tuple(x.shape)} too small for P={P}, M={M}, N={N}")
+    outs = [torch.empty(M, N, dtype=torch.float32, device=dev) for M, N in zip(Ms, Ns)]
+    biases = [torch.empty(M, dtype=torch.float32, device=dev) for M in Ms] if want_bias else None
+    scratch = torch.empty(int(lib().mi_nerf_wgrad_scratch_bytes()), dtype=torch.uint8, device=dev)
+    PP, II = C.c_void_p * n, C.c_int * n
+    ms = C.c_float(0.0)
+    with _guard(dev):
+        check(lib().mi_nerf_wgrad_products(n, PP(*[dev_ptr(d, "delta") for d in deltas]), II(*[d.stride(0) for d in deltas]), II(*Ms),
+                                           PP(*[dev_ptr(x, "x") for x in xs]), II(*[x.stride(0) for x in xs]), II(*Ns), int(P),
+                                           PP(*[dev_ptr(o) for o in outs]), II(*Ns), PP(*[dev_ptr(b) for b in biases]) if want_bias else None,
+                                           dev_ptr(scratch, "scratch", torch.uint8, 16), scratch.numel(), int(iters),
+                                           C.byref(ms) if timed else None, stream_ptr(dev)), "mi_nerf_wgrad_products")
+    return outs, biases, (float(ms.value) if timed else None)
 
 
 def train_views(net: Net, n_rays: int, S: int, stash: Optional[torch.Tensor] = None, work: Optional[torch.Tensor] = None):

@@ -127,6 +127,10 @@ def test_mlp_backward_vs_autograd(D, W, skip, n, S):
         off += want.numel()
         assert rel_err(got, want) < 2e-4, k
     assert off == grads.numel() == ops.param_count(net)
+    # the flat vector is allocated uninitialised (torch.empty): every element must be WRITTEN by the weight-gradient kernels
+    poison = torch.full((ops.param_count(net),), float("nan"), device=DEV)
+    again, _ = ops.mlp_backward(net, packed, packed_bwd, raysd, zd, d_rawd, stash, grads=poison)
+    assert again.data_ptr() == poison.data_ptr() and torch.isfinite(poison).all() and torch.equal(poison, grads)
 
 
 def test_device_pack_matches_host_pack():
@@ -317,6 +321,24 @@ def test_wgrad_product_vs_float64(P, M, N):
     out, bias, _ = ops.wgrad_product(d.to(DEV), M, x.to(DEV), N, P)
     assert rel_err(out, want.float()) < 2e-6 * max(1.0, P ** 0.5 / 10)
     assert rel_err(bias, d[:P, :M].double().sum(0).float()) < 1e-5
+
+
+def test_wgrad_products_batched_entry_equals_the_single_products():
+    """mi_nerf_wgrad_products (several wide products over the same points in one launch -- the form the backward pass uses) against
+    the stand-alone entry, product by product, and against float64."""
+    g = torch.Generator().manual_seed(5)
+    P = 5000
+    shapes = [(256, 256), (256, 128), (128, 256), (200, 252), (256, 256)]
+    deltas = [torch.randn(P + 3, M, generator=g).to(DEV) for M, _ in shapes]
+    xs = [torch.randn(P + 3, N, generator=g).to(DEV) for _, N in shapes]
+    outs, biases, _ = ops.wgrad_products(deltas, xs, P)
+    for d, x, o, b in zip(deltas, xs, outs, biases):
+        o1, b1, _ = ops.wgrad_product(d, d.shape[1], x, x.shape[1], P)
+        want = d[:P].double().T @ x[:P].double()
+        assert rel_err(o, want) < 2e-5 and rel_err(b, d[:P].double().sum(0)) < 2e-5
+        assert rel_err(o, o1) < 1e-5 and rel_err(b, b1) < 1e-5                   # different slice counts: same sums up to summation order
+    with pytest.raises(Exception):
+        ops.wgrad_products([deltas[0][:, :32].contiguous()], [xs[0]], P)            # a narrow side: not for the batched entry
 
 
 def test_wgrad_product_beyond_4GiB_operands():
