@@ -54,7 +54,8 @@ POINTS_PER_RAY = SC + (SC + NF)          # 64 coarse + 192 fine network evaluati
 FLOP_PER_RAY = FLOP_PER_POINT * POINTS_PER_RAY          # 303,824,896
 PEAK_F32_MFMA_TFLOPS = 157.3             # MI355X_MICROARCH.md: 256 CU x 256 FLOP/clk x 2.4 GHz
 PEAK_BF16_MFMA_TFLOPS = 2500.0           # dense bf16 MFMA peak (the headline 5 PF figure includes 2:1 sparsity)
-LDS_DMA_CHIP_TBPS = 6.4                  # chip-wide L2 -> LDS fill rate, default cache policy (MI355X_MICROARCH.md, "ldsdma-fill")
+LDS_DMA_CHIP_TBPS = 34.8                 # chip-wide L2 -> LDS fill rate MEASURED with the kernel's own geometry, 4 waves per CU issuing (tools/mfma_probe6 "dma",
+                                         # profiles/r03_bf16_hybrid_probe.txt); the 6.4 TB/s of MI355X_MICROARCH.md is for one loader wave per CU
 BF16_POINTS_PER_PASS = 256               # mlp_bf16.hip: a workgroup takes 4 waves x 64 points through one pass of the weight stream
 LAUNCHER_GRACE_S = float(os.environ.get("BENCH_LAUNCHER_GRACE_S", "10"))     # SIGTERM -> SIGKILL for the survivors of a failed run
 KERNEL_SOURCES = ("mlp_fp32.hip", "mlp_core.h", "layout.h", "common.h")
@@ -139,8 +140,9 @@ def kernel_build_id() -> str:
 
 
 def bf16_stream(blob, n_points: int, kernel_ms: float) -> dict:
-    """The second bound of the bf16 kernel: every workgroup pulls the whole bf16 weight stream from L2 into LDS once per
-    BF16_POINTS_PER_PASS points (the register file holds no more), so a launch moves passes x stream bytes through the L2 -> LDS path."""
+    """The bf16 kernel's weight stream: every workgroup pulls the whole bf16 stream from L2 into LDS once per BF16_POINTS_PER_PASS
+    points (the register file holds no more), so a launch moves passes x stream bytes through the L2 -> LDS path.  Reported beside
+    the path's measured capacity: the kernel uses a fifth of it (round 2 took the 6.4 TB/s of one loader wave per CU for a ceiling)."""
     import numpy as np
     hdr = blob[:64].cpu().numpy().view(np.uint32)
     stream_bytes = int(hdr[8])
@@ -148,7 +150,7 @@ def bf16_stream(blob, n_points: int, kernel_ms: float) -> dict:
     gb = passes * stream_bytes / 1e9
     tbps = gb / kernel_ms
     return {"bytes_per_pass": stream_bytes, "passes": passes, "GB_per_launch": round(gb, 3), "l2_to_lds_TBps": round(tbps, 2),
-            "chip_lds_dma_rate_TBps": LDS_DMA_CHIP_TBPS, "frac_of_lds_dma_rate": round(tbps / LDS_DMA_CHIP_TBPS, 3)}
+            "chip_lds_dma_rate_TBps_measured": LDS_DMA_CHIP_TBPS, "frac_of_lds_dma_rate": round(tbps / LDS_DMA_CHIP_TBPS, 3)}
 
 
 def worker(args) -> None:
