@@ -51,7 +51,7 @@ int pack_map_bf16(const mi_nerf_net*, int32_t*, size_t);
 int pack_apply_bf16(const mi_nerf_net*, const int32_t*, const float*, void*, size_t, hipStream_t);
 int mlp_rays_fp32(const mi_nerf_net*, const void*, const float*, const float*, int64_t, int, float*, hipStream_t);
 int mlp_embedded_fp32(const mi_nerf_net*, const void*, const float*, int64_t, float*, hipStream_t);
-int mlp_rays_bf16(const mi_nerf_net*, const void*, const float*, const float*, int64_t, int, float*, hipStream_t, int points_per_wave);
+int mlp_rays_bf16(const mi_nerf_net*, const void*, const float*, const float*, int64_t, int, float*, hipStream_t, int points_per_wave, const StratDraw* strat);
 // use_bf16 of mi_nerf_render_cfg / mi_nerf_time_mlp_rays -> launch shape of the bf16 kernel (0: chosen per launch)
 static inline int bf16_points_per_wave(int use_bf16) { return use_bf16 == 2 ? 64 : (use_bf16 == 3 ? 32 : (use_bf16 == 4 ? 832 : 0)); }
 int wgrad_products(int, const float* const*, const int*, const int*, const float* const*, const int*, const int*, int64_t, float* const*, const int*,
@@ -209,11 +209,13 @@ int mi_nerf_mlp_rays(const mi_nerf_net* net, const void* packed, const float* ra
 }
 int mi_nerf_mlp_rays_bf16(const mi_nerf_net* net, const void* packed, const float* rays, const float* z, int64_t n_rays, int S,
                           float* raw, void* st) {
-    return mlp_rays_bf16(net, packed, rays, z, n_rays, S, raw, (hipStream_t)st, 0);
+    MN_CHECK_ARG(z != nullptr || n_rays == 0, "z is NULL");
+    return mlp_rays_bf16(net, packed, rays, z, n_rays, S, raw, (hipStream_t)st, 0, nullptr);
 }
 int mi_nerf_mlp_rays_bf16_shape(const mi_nerf_net* net, const void* packed, const float* rays, const float* z, int64_t n_rays, int S,
                                 float* raw, int points_per_wave, void* st) {
-    return mlp_rays_bf16(net, packed, rays, z, n_rays, S, raw, (hipStream_t)st, points_per_wave);
+    MN_CHECK_ARG(z != nullptr || n_rays == 0, "z is NULL");
+    return mlp_rays_bf16(net, packed, rays, z, n_rays, S, raw, (hipStream_t)st, points_per_wave, nullptr);
 }
 int mi_nerf_composite(const float* raw, const float* z, const float* rays, int ray_stride, int64_t n, int S, float* rgb, float* disp,
                       float* acc, float* weights, float* depth, void* st) {
@@ -344,11 +346,17 @@ int mi_nerf_render_rays(const mi_nerf_net* net, const void* packed_c, const void
     const int Sc = cfg->Sc, St = cfg->Sc + cfg->Nf;
     // 1-a) stratified depths; 2-a) coarse net; 3-a) composite          (nerf_process.py:187-198)
     // t_rand / u NULL: the jitter is drawn inside the consuming kernels (cfg->seed, cfg->ray_offset + ray, sample)
-    if (int rc = stage_stratified(n, Sc, cfg->near_, cfg->far_, t_rand, cfg->seed, cfg->ray_offset, z_c, st)) return rc;
     MN_CHECK_ARG(cfg->use_bf16 >= 0 && cfg->use_bf16 <= 4, "use_bf16 must be 0..4 (got %d)", cfg->use_bf16);
     const int ppw = bf16_points_per_wave(cfg->use_bf16);
-    if (int rc = cfg->use_bf16 ? mlp_rays_bf16(net, packed_c, rays, z_c, n, Sc, raw_c, st, ppw)
-                               : mlp_rays_fp32(net, packed_c, rays, z_c, n, Sc, raw_c, st)) return rc;
+    if (cfg->use_bf16) {
+        // the bf16 kernel draws the stratified depths in its own prologue and writes z_c (one launch fewer: at a 512-ray shard a
+        // launch is ~4 us of a ~130 us step)
+        const StratDraw sd{cfg->near_, cfg->far_, t_rand, cfg->seed, cfg->ray_offset, z_c};
+        if (int rc = mlp_rays_bf16(net, packed_c, rays, nullptr, n, Sc, raw_c, st, ppw, &sd)) return rc;
+    } else {
+        if (int rc = stage_stratified(n, Sc, cfg->near_, cfg->far_, t_rand, cfg->seed, cfg->ray_offset, z_c, st)) return rc;
+        if (int rc = mlp_rays_fp32(net, packed_c, rays, z_c, n, Sc, raw_c, st)) return rc;
+    }
     if (cfg->Nf == 0) return stage_composite(raw_c, z_c, rays, 6, n, Sc, rgb_c, disp_c, nullptr, wts_c, nullptr, st);
     {
         // 3-a) + 1-b) composite, resample + merge in one launch; 2-b) fine net over all Sc+Nf depths; 3-b) composite   (:198-213)
@@ -356,7 +364,7 @@ int mi_nerf_render_rays(const mi_nerf_net* net, const void* packed_c, const void
         float* raw_f = (float*)(w + L.raw_f);
         if (int rc = stage_composite_fine_z(raw_c, z_c, rays, n, Sc, cfg->Nf, cfg->det, u, cfg->seed, cfg->ray_offset, rgb_c, disp_c, wts_c, z_f, st))
             return rc;
-        if (int rc = cfg->use_bf16 ? mlp_rays_bf16(net, packed_f, rays, z_f, n, St, raw_f, st, ppw)
+        if (int rc = cfg->use_bf16 ? mlp_rays_bf16(net, packed_f, rays, z_f, n, St, raw_f, st, ppw, nullptr)
                                    : mlp_rays_fp32(net, packed_f, rays, z_f, n, St, raw_f, st)) return rc;
         if (int rc = stage_composite(raw_f, z_f, rays, 6, n, St, rgb_f, disp_f, nullptr, nullptr, nullptr, st)) return rc;
     }
@@ -373,7 +381,7 @@ int mi_nerf_time_mlp_rays(const mi_nerf_net* net, const void* packed, const floa
     int rc = MI_NERF_OK;
     MN_HIP(hipEventRecord(e0, st));
     for (int i = 0; i < iters && rc == MI_NERF_OK; ++i)
-        rc = use_bf16 ? mlp_rays_bf16(net, packed, rays, z, n_rays, S, raw, st, bf16_points_per_wave(use_bf16)) : mlp_rays_fp32(net, packed, rays, z, n_rays, S, raw, st);
+        rc = use_bf16 ? mlp_rays_bf16(net, packed, rays, z, n_rays, S, raw, st, bf16_points_per_wave(use_bf16), nullptr) : mlp_rays_fp32(net, packed, rays, z, n_rays, S, raw, st);
     MN_HIP(hipEventRecord(e1, st));
     MN_HIP(hipEventSynchronize(e1));
     float ms = 0.f;

@@ -54,6 +54,37 @@ __host__ __device__ inline float counter_uniform(uint32_t seed, uint32_t stream_
 }
 
 // ---------------------------------------------------------------------------------------------
+// stratified coarse depths and their jitter (stages.hip: stratified_kernel; mlp_bf16.hip draws them in its own prologue)
+// ---------------------------------------------------------------------------------------------
+// torch.linspace(0,1,S)[i] in fp32 (symmetric fill: ATen RangeFactories) and z = near*(1-t) + far*t
+__device__ __forceinline__ float strat_edge(int i, int S, float step, float near_, float far_) {
+    const float t = (S == 1) ? 0.0f : (i < S / 2) ? step * (float)i : 1.0f - step * (float)(S - 1 - i);   // steps=1 -> [start]
+    return near_ * (1.0f - t) + far_ * t;               // nerf_process.py:53
+}
+
+// Where a stage's uniforms come from: an explicit [n, S] tensor (injected randomness: parity tests, the training path), or -- values ==
+// NULL -- the counter-based generator evaluated in the consuming kernel itself, keyed on (seed, stream, ray0 + ray, sample): the
+// values mi_nerf_fill_uniform would have written, without the tensor, its launch or its HBM round trip.
+struct Jitter {
+    const float* values;
+    uint32_t seed, stream;
+    long long ray0;
+};
+__device__ __forceinline__ float jitter_at(const Jitter& j, long long ray, int sample, int S) {
+    return j.values ? j.values[ray * S + sample] : counter_uniform(j.seed, j.stream, (uint32_t)(j.ray0 + ray), (uint32_t)sample);
+}
+
+// what a kernel needs to draw the coarse depths itself (host side of mlp_rays_bf16's strat argument)
+struct StratDraw { float near_, far_; const float* t_rand; uint32_t seed; int64_t ray0; float* z_out; };
+// one stratified coarse depth (nerf_process.py:42-60): sample i of S on ray `ray`
+__device__ __forceinline__ float stratified_depth(long long ray, int i, int S, float step, float near_, float far_, const Jitter& t_rand) {
+    const float zi = strat_edge(i, S, step, near_, far_);
+    const float lower = (i == 0) ? zi : 0.5f * (zi + strat_edge(i - 1, S, step, near_, far_));       // :55,57
+    const float upper = (i == S - 1) ? zi : 0.5f * (strat_edge(i + 1, S, step, near_, far_) + zi);   // :55,56
+    return lower + (upper - lower) * jitter_at(t_rand, ray, i, S);     // :60
+}
+
+// ---------------------------------------------------------------------------------------------
 // accurate sin / cos for positional encoding.  Arguments are 2^k * x (exact in fp32) and reach
 // ~3e3 rad for lego, so the reduction matters: 3-term Cody-Waite with FMA (pi/2 = HI + MID + LO),
 // then the Cephes single-precision minimax polynomials on [-pi/4, pi/4].  |error| <~ 1.5e-7.

@@ -306,7 +306,10 @@ struct MlpArgsB {
     const char* stream;
     const float* side;
     const float* rays;
-    const float* z;
+    const float* z;             // [n_rays, S] depths; NULL: the coarse pass draws its own stratified depths (strat_*) and writes them to z_out
+    float* z_out;
+    float strat_near, strat_far, strat_step;
+    Jitter strat_jitter;
     float* out;
     PhaseB ph[2];               // one or two phases (see run_phase); the kernel's template arguments say how many and of which shape
     unsigned n_rays;
@@ -566,7 +569,12 @@ __device__ __forceinline__ void run_phase(const MlpArgsB& a, const PhaseB ph, ch
             for (int e = 0; e < 6; ++e) nx_r[tl][e] = rp[e];
             if (tl == (pq >> 1)) {
                 const int sample = (int)chunk * 32 + 16 * (pq & 1) + col;
-                nx_z = a.z[(size_t)ray * a.S + (sample < a.S ? sample : a.S - 1)];
+                const int sc = sample < a.S ? sample : a.S - 1;
+                if (a.z) nx_z = a.z[(size_t)ray * a.S + sc];
+                else {          // the coarse pass of render_rays: stratified depth drawn here (nerf_process.py:42-60), kept for the compositing
+                    nx_z = stratified_depth((long long)ray, sc, a.S, a.strat_step, a.strat_near, a.strat_far, a.strat_jitter);
+                    if (q4 < NP) a.z_out[(size_t)ray * a.S + sc] = nx_z;      // inactive / clamped lanes rewrite an existing element with its own value
+                }
             }
         }
     };
@@ -996,16 +1004,22 @@ static int launch_bf16(MlpArgsB a, long long split, long long n_wtiles, hipStrea
 }
 
 // points_per_wave: 0 = chosen per launch (pick_np), 64 / 32 = forced (A/B measurements, parity tests of each shape)
+// z_dev == NULL (strat != NULL): the kernel draws the stratified depths of render_rays' coarse pass itself and writes them to strat->z_out
 int mlp_rays_bf16(const mi_nerf_net* net, const void* packed_dev, const float* rays_dev, const float* z_dev, int64_t n_rays, int S,
-                  float* raw_dev, hipStream_t st, int points_per_wave) {
+                  float* raw_dev, hipStream_t st, int points_per_wave, const StratDraw* strat) {
     if (int rc = check_net_bf16(net)) return rc;
     MN_CHECK_ARG(n_rays >= 0 && S >= 1, "bad sizes n_rays=%lld S=%d", (long long)n_rays, S);
     MN_CHECK_ARG(points_per_wave == 0 || points_per_wave == 32 || points_per_wave == 64 || points_per_wave == 832,
                  "points_per_wave must be 0 (auto), 32, 64 or 832 (8 waves of 32) (got %d)", points_per_wave);
     if (n_rays == 0) return MI_NERF_OK;
-    MN_CHECK_ARG(packed_dev && rays_dev && z_dev && raw_dev, "NULL device pointer");
+    MN_CHECK_ARG(packed_dev && rays_dev && raw_dev && (z_dev || (strat && strat->z_out)), "NULL device pointer");
     const BlobLayoutBf16 L = make_layout_bf16(net->D, net->W, net->skip, net->L_x, net->L_d);
     MlpArgsB a{};
+    if (!z_dev) {
+        a.z_out = strat->z_out; a.strat_near = strat->near_; a.strat_far = strat->far_;
+        a.strat_step = S > 1 ? 1.0f / (float)(S - 1) : 0.0f;
+        a.strat_jitter = Jitter{strat->t_rand, strat->seed, 0u, (long long)strat->ray0};
+    }
     a.stream = (const char*)packed_dev + L.stream_off;
     a.side = (const float*)((const char*)packed_dev + L.side_off);
     a.rays = rays_dev; a.z = z_dev; a.out = raw_dev;

@@ -99,34 +99,13 @@ __global__ __launch_bounds__(256) void fill_uniform_kernel(uint32_t seed, uint32
     out[i] = counter_uniform(seed, stream_id, (uint32_t)(ray0 + r), (uint32_t)(i - r * S));
 }
 
-// torch.linspace(0,1,S)[i] in fp32 (symmetric fill: ATen RangeFactories) and z = near*(1-t) + far*t
-__device__ __forceinline__ float strat_edge(int i, int S, float step, float near_, float far_) {
-    const float t = (S == 1) ? 0.0f : (i < S / 2) ? step * (float)i : 1.0f - step * (float)(S - 1 - i);   // steps=1 -> [start]
-    return near_ * (1.0f - t) + far_ * t;               // nerf_process.py:53
-}
-
-// Where a stage's uniforms come from: an explicit [n, S] tensor (injected randomness: parity tests, the training path), or -- values ==
-// NULL -- the counter-based generator evaluated in the consuming kernel itself, keyed on (seed, stream, ray0 + ray, sample): the
-// values mi_nerf_fill_uniform would have written, without the tensor, its launch or its HBM round trip.
-struct Jitter {
-    const float* values;
-    uint32_t seed, stream;
-    long long ray0;
-};
-__device__ __forceinline__ float jitter_at(const Jitter& j, long long ray, int sample, int S) {
-    return j.values ? j.values[ray * S + sample] : counter_uniform(j.seed, j.stream, (uint32_t)(j.ray0 + ray), (uint32_t)sample);
-}
-
 __global__ __launch_bounds__(256) void stratified_kernel(long long total, int S, float near_, float far_, float step,
                                                           Jitter t_rand, float* __restrict__ z) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
     const long long ray = idx / S;
     const int i = (int)(idx - ray * S);
-    const float zi = strat_edge(i, S, step, near_, far_);
-    const float lower = (i == 0) ? zi : 0.5f * (zi + strat_edge(i - 1, S, step, near_, far_));       // :55,57
-    const float upper = (i == S - 1) ? zi : 0.5f * (strat_edge(i + 1, S, step, near_, far_) + zi);   // :55,56
-    z[idx] = lower + (upper - lower) * jitter_at(t_rand, ray, i, S);     // :60
+    z[idx] = stratified_depth(ray, i, S, step, near_, far_, t_rand);
 }
 
 // ------------------------------------------------------------------------------------------------

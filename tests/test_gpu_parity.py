@@ -692,6 +692,14 @@ def test_in_kernel_jitter_equals_explicit_tensors(bf16, packed_big, lego_rays):
     assert d0["_u"] is None and torch.equal(ops.fine_z(d0["_z_c"], d0["_weights_c"], 128, True, None), d0["_z_f"])
     e0 = NP.render_rays(rays, packed_big, None, make_opts(N_samples_f=0), seed=9, ray_offset=first, bf16=bf16)
     assert "rgb_f" not in e0 and torch.equal(e0["rgb_c"], a["rgb_c"])
+    # sample counts that are not multiples of the 32-sample tile (the bf16 kernel draws the coarse depths in its own prologue)
+    for n2, Sc, Nf in ((77, 40, 24), (3, 33, 7), (130, 16, 16)):
+        o2 = make_opts(N_samples_c=Sc, N_samples_f=Nf)
+        r2 = lego_rays[:n2].contiguous()
+        x = NP.render_rays(r2, packed_big, None, o2, seed=4, ray_offset=99, bf16=bf16, return_intermediates=True)
+        y = NP.render_rays(r2, packed_big, None, o2, seed=4, ray_offset=99, bf16=bf16)
+        assert torch.equal(x["_z_c"], ops.stratified_z(o2.near, o2.far, ops.fill_uniform(4, 0, 99, n2, Sc, DEV)))
+        assert torch.equal(x["rgb_f"], y["rgb_f"]) and torch.equal(x["disp_c"], y["disp_c"]) and torch.isfinite(y["rgb_f"]).all()
 
 
 def test_config2_all_rays_vs_oracle(packed_big, lego_rays):
