@@ -34,9 +34,11 @@ const char* mi_nerf_last_error(void);
 /* ------------------------------------------------------------------------------------------------
  * Network description.  One NeRFModule: D trunk layers of width W, skip-concat of the encoded
  * position after trunk layer `skip` (so trunk layer skip+1 takes [gamma(x), h]), density / feature /
- * view-direction / colour heads (model/NeRF.py:10-52).  Supported by the kernels: W in {128, 256},
- * 2 <= D <= 16, L_x = 10, L_d = 4, at most one skip (skip = -1: none; a skip index >= D-1 never fires,
- * exactly like the reference's `range(D-1)` construction at model/NeRF.py:25).
+ * view-direction / colour heads (model/NeRF.py:10-52).  Supported by the kernels: W in {128, 256} (bf16 variant: 256),
+ * 2 <= D <= 16, L_x <= 10, L_d <= 4 (the kernels evaluate gamma_10 / gamma_4; gamma_L is a prefix of them in the reference's
+ * channel order, PositionalEncoding.py:18-24, so a network with fewer frequencies is packed with zero weights on the rest and
+ * gives the same result), at most one skip (skip = -1: none; a skip index >= D-1 never fires, exactly like the reference's
+ * `range(D-1)` construction at model/NeRF.py:25).  Pre-embedded rows (mi_nerf_mlp_embedded) have the network's own width.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct mi_nerf_net {
     int32_t D;      /* trunk depth             (opts.netDepth, config.py:56) */

@@ -32,6 +32,12 @@ constexpr uint32_t BLOB_MAGIC = 0x4D494E46u;          // 'MINF'
 
 __host__ __device__ constexpr int pe_ksteps(int L) { return ((3 * L + 2 + 3) / 4) * 4; }   // padded to 4
 
+// The kernels are instantiated for L_x = 10, L_d = 4 (the reference's defaults, config.py:54-55).  A network with FEWER frequencies
+// (--L_x / --L_d below the defaults) runs on the same kernels: gamma_L is a prefix of gamma_10 in the reference's channel order
+// (PositionalEncoding.py:18-24), so the packer lays the stream out for 10 / 4 and gives the missing channels zero weights -- the
+// kernel evaluates the full encoding, the extra products add exact zeros.  More frequencies than 10 / 4 are refused.
+constexpr int KERNEL_LX = 10, KERNEL_LD = 4;
+
 struct BlobLayout {
     // all byte offsets from the blob start
     uint32_t stream_off;          // == HEADER_BYTES
@@ -54,7 +60,8 @@ struct BlobLayout {
 __host__ __device__ inline uint32_t round_up_u32(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
 
 // elem_bytes: 4 (fp32 stream) or 2 (bf16 stream; quads keep 1 KiB, see mlp_bf16.hip)
-inline BlobLayout make_layout(int D, int W, int skip, int L_x, int L_d) {
+inline BlobLayout make_layout(int D, int W, int skip, int /*L_x*/, int /*L_d*/) {
+    constexpr int L_x = KERNEL_LX, L_d = KERNEL_LD;              // the layout is the kernels', whatever the network's own L (see above)
     BlobLayout b{};
     const int NT = W / 32;
     const int in_d = 3 + 6 * L_d;

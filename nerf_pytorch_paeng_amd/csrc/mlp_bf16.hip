@@ -81,7 +81,8 @@ struct BlobLayoutBf16 {
     uint32_t bias_trunk, bias_feat, bias_d, head_b, wdir_t, total_bytes;
 };
 
-static BlobLayoutBf16 make_layout_bf16(int D, int W, int skip, int L_x, int L_d) {
+static BlobLayoutBf16 make_layout_bf16(int D, int W, int skip, int /*L_x*/, int /*L_d*/) {
+    constexpr int L_x = KERNEL_LX, L_d = KERNEL_LD;          // the kernel's layout; a network with fewer frequencies gets zero weights (layout.h)
     BlobLayoutBf16 b{};
     const int NT = W / MT, in_d = 3 + 6 * L_d;
     const uint32_t pe_q = (uint32_t)enc_ksteps32(L_x) * NT, h_q = (uint32_t)(W / KF) * NT;
@@ -129,8 +130,8 @@ static void emit_quad(std::vector<T>& st, const float* Wm, int n_out, int n_in, 
             st.push_back((col >= 0 && n >= 0 && n < n_out) ? stream_elem<T>(Wm[(size_t)n * n_in + col]) : (T)0);
         }
 }
-static std::vector<int> enc_cols32(int L, int base) {
-    const int nch = 3 + 6 * L, KS = enc_ksteps32(L);
+static std::vector<int> enc_cols32(int L, int base) {           // L: the network's own frequencies; the k-step count is the kernel's
+    const int nch = 3 + 6 * L, KS = enc_ksteps32(KERNEL_LX);
     std::vector<int> c(KS * KF);
     for (int u = 0; u < KS * KF; ++u) c[u] = u < nch ? base + u : -1;
     return c;
@@ -154,7 +155,8 @@ static void emit_layer(std::vector<T>& st, const float* Wm, int n_out, int n_in,
 static int check_net_bf16(const mi_nerf_net* net) {
     MN_CHECK_ARG(net != nullptr, "net is NULL");
     MN_CHECK_ARG(net->W == 256, "the bf16 variant is built for W=256 only (got %d)", net->W);
-    MN_CHECK_ARG(net->D >= 2 && net->D <= 16 && net->L_x == 10 && net->L_d == 4 && net->skip >= -1, "unsupported network for bf16");
+    MN_CHECK_ARG(net->D >= 2 && net->D <= 16 && net->L_x >= 0 && net->L_x <= KERNEL_LX && net->L_d >= 0 && net->L_d <= KERNEL_LD && net->skip >= -1,
+                 "unsupported network for bf16 (D=%d L_x=%d L_d=%d skip=%d)", net->D, net->L_x, net->L_d, net->skip);
     return MI_NERF_OK;
 }
 
@@ -211,7 +213,8 @@ static void fill_side(const mi_nerf_net* net, const mi_nerf_params* p, const Blo
 }
 static void fill_header(const mi_nerf_net* net, const BlobLayoutBf16& L, uint32_t* hdr) {
     memset(hdr, 0, HEADER_BYTES);
-    hdr[0] = BLOB_MAGIC; hdr[1] = 3; hdr[2] = net->D; hdr[3] = net->W; hdr[4] = (uint32_t)net->skip; hdr[5] = net->L_x; hdr[6] = net->L_d;
+    hdr[0] = BLOB_MAGIC; hdr[1] = 3; hdr[2] = net->D; hdr[3] = net->W; hdr[4] = (uint32_t)net->skip; hdr[5] = KERNEL_LX; hdr[6] = KERNEL_LD;   // the layout's
+    hdr[13] = net->L_x; hdr[14] = net->L_d;                                                                                                    // the network's
     hdr[7] = L.stream_off; hdr[8] = L.stream_bytes; hdr[9] = L.stream_bytes; hdr[10] = L.side_off; hdr[11] = L.side_floats;
     hdr[12] = 2;   // stream element bytes
 }

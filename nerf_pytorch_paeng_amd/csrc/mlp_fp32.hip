@@ -29,7 +29,8 @@ struct MlpArgs {
     const float* side;        // device: blob + side_off
     const float* rays;        // MODE 0: [n_rays, 6]
     const float* z;           // MODE 0: [n_rays, S]
-    const float* x;           // MODE 1: [n_pts, in_x + in_d]
+    const float* x;           // MODE 1: [n_pts, in_x + in_d] with the NETWORK's own widths in_x = 3 + 6 Lx_net, in_d = 3 + 6 Ld_net
+    int Lx_net, Ld_net;       // the network's frequencies (<= the kernel's LX / LD; the missing channels carry zero weights, layout.h)
     float* out;               // [n_pts, 4]
     long long n_wtiles;       // 32-point wave tiles
     long long n_pts;          // MODE 1
@@ -69,13 +70,14 @@ __device__ __forceinline__ void encode_regs(float (&pe)[NPE], const float (&p)[3
     for (int s = 3 * L + 2; s < NPE; ++s) pe[s] = 0.0f;
 }
 
-// gather the same registers from a pre-embedded row (MODE 1)
+// gather the same registers from a pre-embedded row (MODE 1); the row holds L_net <= L frequencies: the others read as zero
 template <int L, int NPE>
-__device__ __forceinline__ void gather_regs(float (&pe)[NPE], const float* row, int hh, bool valid) {
+__device__ __forceinline__ void gather_regs(float (&pe)[NPE], const float* row, int hh, bool valid, int L_net) {
 #pragma unroll
     for (int s = 0; s < 3 * L; ++s) {
         const int ch = 3 + 6 * (s / 3) + (s % 3) + 3 * hh;
-        pe[s] = valid ? row[ch] : 0.0f;
+        const bool have = valid && (s / 3) < L_net;
+        pe[s] = have ? row[have ? ch : 0] : 0.0f;
     }
     pe[3 * L] = valid ? row[hh] : 0.0f;
     pe[3 * L + 1] = (valid && !hh) ? row[2] : 0.0f;
@@ -93,7 +95,7 @@ void mlp_fp32_kernel(const MlpArgs a) {
     constexpr int HN = W / 2;           // activation registers per lane
     constexpr int KPE = pe_ksteps(LX);  // 32
     constexpr int KDE = pe_ksteps(LD);  // 16
-    constexpr int IN_X = 3 + 6 * LX, IN_D = 3 + 6 * LD;
+    constexpr int IN_D = 3 + 6 * LD;
     // groups (t) of a k-quad that carry the training hooks: ReLU' bits, their merge, the row store
 #if defined(MN_HK_B)
     constexpr int HK_B = MN_HK_B, HK_M = MN_HK_M, HK_S = MN_HK_S;          // A/B variant
@@ -237,9 +239,10 @@ void mlp_fp32_kernel(const MlpArgs a) {
             const long long p0 = wt * 32 + col;
             valid = wave_active && p0 < a.n_pts;
             out_idx = p0 < a.n_pts ? p0 : a.n_pts - 1;
-            const float* row = a.x + out_idx * (IN_X + IN_D);
-            gather_regs<LX>(pe, row, hh, true);
-            gather_regs<LD>(de, row + IN_X, hh, true);
+            const int in_x_net = 3 + 6 * a.Lx_net;
+            const float* row = a.x + out_idx * (in_x_net + 3 + 6 * a.Ld_net);
+            gather_regs<LX>(pe, row, hh, true, a.Lx_net);
+            gather_regs<LD>(de, row + in_x_net, hh, true, a.Ld_net);
         }
 
         MN_STAMP(0);   // prologue
@@ -364,7 +367,8 @@ static int check_net(const mi_nerf_net* net) {
     MN_CHECK_ARG(net != nullptr, "net is NULL");
     MN_CHECK_ARG(net->W == 256 || net->W == 128, "unsupported width W=%d (kernels exist for 128 and 256)", net->W);
     MN_CHECK_ARG(net->D >= 2 && net->D <= 16, "unsupported depth D=%d", net->D);
-    MN_CHECK_ARG(net->L_x == 10 && net->L_d == 4, "unsupported encoding L_x=%d L_d=%d (kernels exist for 10/4)", net->L_x, net->L_d);
+    MN_CHECK_ARG(net->L_x >= 0 && net->L_x <= KERNEL_LX && net->L_d >= 0 && net->L_d <= KERNEL_LD,
+                 "unsupported encoding L_x=%d L_d=%d (the kernels evaluate up to %d / %d frequencies)", net->L_x, net->L_d, KERNEL_LX, KERNEL_LD);
     MN_CHECK_ARG(net->skip >= -1, "bad skip=%d", net->skip);
     return MI_NERF_OK;
 }
@@ -445,6 +449,7 @@ static void fill_common(MlpArgs& a, const mi_nerf_net* net, const void* packed_d
     a.stream = (const char*)packed_dev + L.stream_off;
     a.side = (const float*)((const char*)packed_dev + L.side_off);
     a.D = net->D;
+    a.Lx_net = net->L_x; a.Ld_net = net->L_d;
     a.skip_layer = (net->skip >= 0 && net->skip + 1 < net->D) ? net->skip + 1 : -1;
     a.stream_bytes = full_stream ? L.stream_bytes_full : L.stream_bytes_hoist;
     a.side_floats = L.side_floats;

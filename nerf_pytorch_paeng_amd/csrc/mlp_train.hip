@@ -781,7 +781,7 @@ int mlp_backward_fp32(const mi_nerf_net* net, const void* packed_fwd, const void
                       int64_t n_rays, int S, const float* d_raw, const void* stash, void* work, size_t work_bytes, float* grads,
                       int stage, hipStream_t st, const float* x_dev, int64_t n_rows) {
     MN_CHECK_ARG(net != nullptr, "net is NULL");
-    MN_CHECK_ARG(net->L_x == 10 && net->L_d == 4, "unsupported encoding L_x=%d L_d=%d", net->L_x, net->L_d);
+    MN_CHECK_ARG(net->L_x >= 0 && net->L_x <= KERNEL_LX && net->L_d >= 0 && net->L_d <= KERNEL_LD, "unsupported encoding L_x=%d L_d=%d", net->L_x, net->L_d);
     MN_CHECK_ARG(net->skip >= -1, "bad skip=%d", net->skip);
     MN_CHECK_ARG(n_rays >= 0 && S >= 1, "bad sizes n_rays=%lld S=%d", (long long)n_rays, S);
     const long long Ppad = (long long)n_rays * S;                  // rows per layer in the stash / delta buffers

@@ -15,16 +15,18 @@ namespace {
 
 struct KStep { int lo, hi; };   // input column fed by lane half 0 / 1; -1 = zero pad
 
-// k-steps over an encoded 3-vector gamma(.) occupying columns [base, base+3+6L)
-std::vector<KStep> enc_ksteps(int L, int base) {
+// k-steps of the KERNEL's encoding (LK frequencies) over a network input gamma_L(.) (L <= LK) occupying columns [base, base+3+6L):
+// the frequencies the network does not have get zero weights
+std::vector<KStep> enc_ksteps(int LK, int L, int base) {
     std::vector<KStep> ks;
-    for (int s = 0; s < 3 * L; ++s) {
+    for (int s = 0; s < 3 * LK; ++s) {
         const int k = s / 3, c = s % 3;
-        ks.push_back({base + 3 + 6 * k + c, base + 3 + 6 * k + 3 + c});   // (sin, cos) of 2^k p_c
+        if (k < L) ks.push_back({base + 3 + 6 * k + c, base + 3 + 6 * k + 3 + c});   // (sin, cos) of 2^k p_c
+        else ks.push_back({-1, -1});
     }
     ks.push_back({base + 0, base + 1});
     ks.push_back({base + 2, -1});
-    while ((int)ks.size() < pe_ksteps(L)) ks.push_back({-1, -1});
+    while ((int)ks.size() < pe_ksteps(LK)) ks.push_back({-1, -1});
     return ks;
 }
 
@@ -86,21 +88,22 @@ int pack_fp32(const mi_nerf_net* net, const mi_nerf_params* p, void* blob, size_
 
     std::vector<float> stream;
     stream.reserve(L.stream_bytes_full / 4);
-    emit_part(stream, p->linear_x_w[0], W, in_x, NT, enc_ksteps(net->L_x, 0));
+    emit_part(stream, p->linear_x_w[0], W, in_x, NT, enc_ksteps(KERNEL_LX, net->L_x, 0));
     for (int l = 1; l < D; ++l) {
         const bool cat = (net->skip >= 0 && l == net->skip + 1);
         const int n_in = cat ? W + in_x : W;
-        if (cat) emit_part(stream, p->linear_x_w[l], W, n_in, NT, enc_ksteps(net->L_x, 0));   // [gamma(x), h]
+        if (cat) emit_part(stream, p->linear_x_w[l], W, n_in, NT, enc_ksteps(KERNEL_LX, net->L_x, 0));   // [gamma(x), h]
         emit_part(stream, p->linear_x_w[l], W, n_in, NT, act_ksteps(W, cat ? in_x : 0));
     }
     emit_part(stream, p->linear_feat_w, W, W, NT, act_ksteps(W, 0));
     emit_part(stream, p->linear_d_w, W / 2, W + in_d, NT / 2, act_ksteps(W, 0));                // [feature, gamma(d)]
     MN_CHECK_ARG(stream.size() * 4 == L.stream_bytes_hoist, "internal: hoisted stream %zu != %u", stream.size() * 4, L.stream_bytes_hoist);
-    emit_part(stream, p->linear_d_w, W / 2, W + in_d, NT / 2, enc_ksteps(net->L_d, W));
+    emit_part(stream, p->linear_d_w, W / 2, W + in_d, NT / 2, enc_ksteps(KERNEL_LD, net->L_d, W));
     MN_CHECK_ARG(stream.size() * 4 == L.stream_bytes_full, "internal: full stream %zu != %u", stream.size() * 4, L.stream_bytes_full);
 
     uint32_t* hdr = (uint32_t*)blob;
-    hdr[0] = BLOB_MAGIC; hdr[1] = 1; hdr[2] = D; hdr[3] = W; hdr[4] = (uint32_t)net->skip; hdr[5] = net->L_x; hdr[6] = net->L_d;
+    hdr[0] = BLOB_MAGIC; hdr[1] = 1; hdr[2] = D; hdr[3] = W; hdr[4] = (uint32_t)net->skip; hdr[5] = KERNEL_LX; hdr[6] = KERNEL_LD;   // the LAYOUT's L
+    hdr[13] = net->L_x; hdr[14] = net->L_d;                                                                                            // the network's
     hdr[7] = L.stream_off; hdr[8] = L.stream_bytes_hoist; hdr[9] = L.stream_bytes_full; hdr[10] = L.side_off; hdr[11] = L.side_floats;
     hdr[12] = 4;   // stream element bytes
     memcpy((char*)blob + L.stream_off, stream.data(), L.stream_bytes_full);

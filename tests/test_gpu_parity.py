@@ -518,6 +518,58 @@ def test_other_network_shapes(D, W):
     assert err(raw, ref) <= 1e-4
 
 
+@pytest.mark.parametrize("W,L_x,L_d", [(256, 6, 2), (256, 10, 0), (256, 0, 4), (128, 4, 4), (128, 8, 1)])
+def test_fewer_encoding_frequencies(W, L_x, L_d, lego_rays):
+    """--L_x / --L_d below the defaults (config.py:54-55).  gamma_L is a prefix of gamma_10 in the reference's channel order
+    (PositionalEncoding.py:18-24), so such a network runs on the kernels built for 10 / 4 with zero weights on the frequencies it
+    does not have: embedded rows of the network's own width, the fused rays path, the bf16 variant, the training gradients."""
+    D = 8 if W == 256 else 4
+    in_x, in_d = 3 + 6 * L_x, 3 + 6 * L_d
+    sd = synthetic.make_state_dict(41 + L_x, D, W, in_x=in_x, in_d=in_d)
+    packed = weights.PackedNeRF.from_state_dict(sd, DEV)
+    assert (packed.net.L_x, packed.net.L_d, packed.net.skip) == (L_x, L_d, 4 if D >= 6 else -1)
+    n, S = 19, 48
+    rays = lego_rays[:n].contiguous()
+    z = torch.sort(T(R.counter_uniform(8, 0, 0, n, S)) * 4 + 2, -1)[0]
+    x = R.embed(rays.cpu(), z, L_x, L_d)                                   # [n*S, in_x + in_d]: the network's own row width
+    assert x.shape[1] == in_x + in_d
+    ref = R.mlp_forward(sd, "model_fine.", x.double(), D, in_x, in_d, dtype=torch.float64)
+    y = ops.mlp_embedded(packed.net, packed.fine, x.to(DEV))
+    assert err(y, ref) <= 1e-4, err(y, ref)
+    assert torch.equal(ops.embed(rays, z.to(DEV), L_x, L_d).cpu()[:, :3], x[:, :3])
+    raw = ops.mlp_rays(packed.net, packed.fine, rays, z.to(DEV))
+    assert err(raw.reshape(-1, 4), ref) <= 2e-4, err(raw.reshape(-1, 4), ref)
+    if W == 256:
+        ref16 = R.mlp_forward_bf16(sd, "model_fine.", x, D, in_x, in_d)
+        raw16 = ops.mlp_rays(packed.net, packed.bf16()[1], rays, z.to(DEV), bf16=True).cpu().reshape(-1, 4)
+        e = (raw16 - ref16).abs()
+        rel = max(float(e[:, c].mean() / ref16[:, c].abs().mean()) for c in range(4))
+        assert rel < 2e-3 and float(e.max()) < 0.2, (rel, float(e.max()))
+    # the drop-in surface with a model of that shape, inference and one training step's gradients
+    model = NeRF(D, W, in_x, in_d).to(DEV)
+    model.load_state_dict({k: T(v) for k, v in sd.items()})
+    opts = make_opts(N_samples_c=16, N_samples_f=16)
+    posenc = (get_positional_encoder(L_x)[0], get_positional_encoder(L_d)[0])
+    with torch.no_grad():
+        out = NP.render_rays(rays, model, posenc, opts, seed=2, return_intermediates=True)
+    want = R.render_rays(rays.cpu(), sd, R.PathConfig(N_samples_c=16, N_samples_f=16, L_x=L_x, L_d=L_d, netDepth=D, netWidth=W),
+                         out["_t_rand"].cpu(), out["_u"].cpu())
+    assert err(out["rgb_c"], want["rgb_c"]) <= 2e-5
+    tgt = torch.rand(n, 3, generator=torch.Generator().manual_seed(1))
+    psd = {k: T(v).clone().float().requires_grad_(True) for k, v in sd.items()}
+    ref_t = R.render_rays(rays.cpu(), psd, R.PathConfig(N_samples_c=16, N_samples_f=16, L_x=L_x, L_d=L_d, netDepth=D, netWidth=W),
+                          out["_t_rand"].cpu(), out["_u"].cpu())
+    torch.mean((ref_t["rgb_c"] - tgt) ** 2).backward()
+    got = NP.render_rays(rays, model, posenc, opts, t_rand=out["_t_rand"], u=out["_u"])
+    torch.mean((got["rgb_c"] - tgt.to(DEV)) ** 2).backward()
+    for k, p_ in model.model_coarse.named_parameters():
+        g_ref = psd["model_coarse." + k].grad
+        assert p_.grad.shape == g_ref.shape
+        assert float((p_.grad.cpu() - g_ref).abs().max()) <= 2e-4 * float(g_ref.abs().max()) + 1e-9, k
+    with pytest.raises(Exception):
+        weights.PackedNeRF.from_state_dict(synthetic.make_state_dict(1, 4, 128, in_x=3 + 6 * 11), DEV)      # more than 10 frequencies
+
+
 def test_frame_harness_rows_and_llff(packed_big):
     """dist.render_frame (the counterpart of test.py:38-53) on one process: a frame rendered whole equals the same frame
     rendered as two row blocks with global ray offsets; llff mode runs the NDC warp."""
