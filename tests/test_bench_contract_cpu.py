@@ -10,7 +10,9 @@ REQUIRED = {"metric": str, "value": (int, float), "unit": str, "n_gpus": int, "s
             "higher_is_better": bool, "scaling": str, "dtype": str, "data": str, "config": dict, "roofline": dict}
 
 
-@pytest.mark.parametrize("name", ["r02_bench_n1.json", "r02_bench_n1_bf16.json", "r02_bench_n1_fern.json", "r02_bench_n2_gloo_rehearsal.json"])
+@pytest.mark.parametrize("name", ["r02_bench_n1.json", "r02_bench_n1_bf16.json", "r02_bench_n1_fern.json", "r02_bench_n2_gloo_rehearsal.json",
+                                  "r03_bench_n1.json", "r03_bench_n1_bf16.json", "r03_bench_n1_fern.json", "r03_bench_n4_gloo_rehearsal.json",
+                                  "r03_bench_rank3_of_8_alone.json"])
 def test_committed_bench_line_has_the_contract_fields(name):
     path = os.path.join(ROOT, "profiles", name)
     with open(path) as f:
@@ -28,6 +30,10 @@ def test_committed_bench_line_has_the_contract_fields(name):
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 2e-3
     # whole-job rate: rays of the (strong-scaled) batch per step time
     assert abs(line["value"] - 4096 / (line["ms_per_step"] * 1e-3)) / line["value"] < 2e-3
+    if name == "r03_bench_n1.json":                       # the default line carries the bf16 small-batch leg and both weight-gradient legs
+        assert [l["rays"] for l in line["bf16"]["small_batch"]] == [256, 512, 1024, 2048]
+        assert {"wgrad_256x256", "wgrad_9x256x256"} <= set(line["train"])
+        assert line["roofline"]["traffic_is_current"] is True
     if line["n_gpus"] == 1 and "cpu_baseline" in line:
         cpu = line["cpu_baseline"]
         for key in ("value", "unit", "cores", "kind", "sample"):
