@@ -140,6 +140,16 @@ int mi_nerf_mlp_rays_bf16(const mi_nerf_net* net, const void* packed_bf16_dev, c
 int mi_nerf_mlp_rays_bf16_shape(const mi_nerf_net* net, const void* packed_bf16_dev, const float* rays_dev,
                                 const float* z_dev, int64_t n_rays, int S, float* raw_dev, int points_per_wave, void* stream);
 
+/* SPLIT-PRECISION variant of the fused entry: fp32-grade results on the f16 matrix pipe (gfx950 has no xf32 / TF32; its f32-input MFMA
+ * runs at 1/16 of the f16 rate).  Weights and activations travel as f16 pairs x = hi + lo * 2^-11, a product is three
+ * v_mfma_f32_16x16x32_f16 with fp32 accumulation (hi.hi, hi.lo, lo.hi; the dropped lo.lo term is 2^-22 of the product): the error
+ * against an fp64 evaluation is that of the fp32 kernel.  W = 256; |weights| and |activations| must stay below the f16 maximum
+ * (65 504; the packer refuses larger weights).  An extra precision mode like the bf16 variant, not the default path. */
+size_t mi_nerf_packed_bytes_f16s(const mi_nerf_net* net);
+int mi_nerf_pack_weights_f16s(const mi_nerf_net* net, const mi_nerf_params* params, void* host_blob, size_t blob_bytes);
+int mi_nerf_mlp_rays_f16s(const mi_nerf_net* net, const void* packed_f16s_dev, const float* rays_dev, const float* z_dev,
+                          int64_t n_rays, int S, float* raw_dev, void* stream);
+
 /* a10 post_process(outputs, z_vals, rays_d)                              nerf_process.py:89-140
  * raw [n,S,4], z [n,S], rays [n, ray_stride] with the direction at floats 3..5 when ray_stride == 6, or a
  * bare [n,3] direction tensor when ray_stride == 3.  Any of acc/weights/depth may be NULL. */
@@ -161,7 +171,8 @@ typedef struct mi_nerf_render_cfg {
     int32_t Sc, Nf;        /* opts.N_samples_c / _f  (config.py:72-73)       */
     int32_t det;           /* opts.perturb == 0.     (nerf_process.py:65)    */
     int32_t use_bf16;      /* 0: fp32 MFMA (default); 1: bf16 MFMA variant, launch shape chosen per launch;
-                              2 / 3: bf16 with 64 / 32 points per wave pinned (A/B measurements) */
+                              2 / 3: bf16 with 64 / 32 points per wave pinned (A/B measurements);
+                              5: f16 split precision (mi_nerf_mlp_rays_f16s; blobs from mi_nerf_pack_weights_f16s) */
     uint32_t seed;         /* in-kernel jitter (t_rand / u NULL): generator seed ...             */
     uint32_t reserved;     /* must be 0                                                          */
     int64_t ray_offset;    /* ... and the GLOBAL index of ray 0 (chunk / shard invariant frames) */

@@ -73,6 +73,9 @@ SIGNATURES = {
     "mi_nerf_mlp_rays": (_I, [_NETP, _P, _P, _P, _I64, _I, _P, _P]),
     "mi_nerf_mlp_rays_bf16": (_I, [_NETP, _P, _P, _P, _I64, _I, _P, _P]),
     "mi_nerf_mlp_rays_bf16_shape": (_I, [_NETP, _P, _P, _P, _I64, _I, _P, _I, _P]),
+    "mi_nerf_packed_bytes_f16s": (_SZ, [_NETP]),
+    "mi_nerf_pack_weights_f16s": (_I, [_NETP, C.POINTER(Params), _P, _SZ]),
+    "mi_nerf_mlp_rays_f16s": (_I, [_NETP, _P, _P, _P, _I64, _I, _P, _P]),
     "mi_nerf_composite": (_I, [_P, _P, _P, _I, _I64, _I, _P, _P, _P, _P, _P, _P]),
     "mi_nerf_render_workspace_bytes": (_SZ, [_CFGP, _I64]),
     "mi_nerf_render_rays": (_I, [_NETP, _P, _P, _CFGP, _P, _I64, _P, _P, _P, _SZ, _P, _P, _P, _P, _P]),

@@ -52,6 +52,12 @@ int pack_apply_bf16(const mi_nerf_net*, const int32_t*, const float*, void*, siz
 int mlp_rays_fp32(const mi_nerf_net*, const void*, const float*, const float*, int64_t, int, float*, hipStream_t);
 int mlp_embedded_fp32(const mi_nerf_net*, const void*, const float*, int64_t, float*, hipStream_t);
 int mlp_rays_bf16(const mi_nerf_net*, const void*, const float*, const float*, int64_t, int, float*, hipStream_t, int points_per_wave, const StratDraw* strat);
+size_t packed_bytes_f16s(const mi_nerf_net*);
+int pack_f16s(const mi_nerf_net*, const mi_nerf_params*, void*, size_t);
+int mlp_rays_f16s(const mi_nerf_net*, const void*, const float*, const float*, int64_t, int, float*, hipStream_t);
+// the MLP launch of a given precision mode (mi_nerf_render_cfg.use_bf16 / mi_nerf_time_mlp_rays): 0 fp32 MFMA; 1..4 bf16 (launch shape);
+// 5 f16 split precision (fp32-grade results on the f16 matrix pipe, mlp_f16s.hip)
+#define MI_NERF_MODE_F16S 5
 // use_bf16 of mi_nerf_render_cfg / mi_nerf_time_mlp_rays -> launch shape of the bf16 kernel (0: chosen per launch)
 static inline int bf16_points_per_wave(int use_bf16) { return use_bf16 == 2 ? 64 : (use_bf16 == 3 ? 32 : (use_bf16 == 4 ? 832 : 0)); }
 int wgrad_products(int, const float* const*, const int*, const int*, const float* const*, const int*, const int*, int64_t, float* const*, const int*,
@@ -163,6 +169,13 @@ size_t mi_nerf_packed_bytes_bf16(const mi_nerf_net* net) {
     if (check_net_basic(net)) return 0;
     return packed_bytes_bf16(net);
 }
+size_t mi_nerf_packed_bytes_f16s(const mi_nerf_net* net) {
+    return packed_bytes_f16s(net);
+}
+int mi_nerf_pack_weights_f16s(const mi_nerf_net* net, const mi_nerf_params* params, void* blob, size_t bytes) {
+    MN_CHECK_ARG(net && params && blob, "NULL argument");
+    return pack_f16s(net, params, blob, bytes);
+}
 int mi_nerf_pack_weights_bf16(const mi_nerf_net* net, const mi_nerf_params* params, void* blob, size_t bytes) {
     if (int rc = check_net_basic(net)) return rc;
     MN_CHECK_ARG(params && blob, "NULL params/blob");
@@ -212,6 +225,10 @@ int mi_nerf_mlp_rays_bf16(const mi_nerf_net* net, const void* packed, const floa
                           float* raw, void* st) {
     MN_CHECK_ARG(z != nullptr || n_rays == 0, "z is NULL");
     return mlp_rays_bf16(net, packed, rays, z, n_rays, S, raw, (hipStream_t)st, 0, nullptr);
+}
+int mi_nerf_mlp_rays_f16s(const mi_nerf_net* net, const void* packed, const float* rays, const float* z, int64_t n_rays, int S, float* raw,
+                          void* st) {
+    return mlp_rays_f16s(net, packed, rays, z, n_rays, S, raw, (hipStream_t)st);
 }
 int mi_nerf_mlp_rays_bf16_shape(const mi_nerf_net* net, const void* packed, const float* rays, const float* z, int64_t n_rays, int S,
                                 float* raw, int points_per_wave, void* st) {
@@ -347,16 +364,17 @@ int mi_nerf_render_rays(const mi_nerf_net* net, const void* packed_c, const void
     const int Sc = cfg->Sc, St = cfg->Sc + cfg->Nf;
     // 1-a) stratified depths; 2-a) coarse net; 3-a) composite          (nerf_process.py:187-198)
     // t_rand / u NULL: the jitter is drawn inside the consuming kernels (cfg->seed, cfg->ray_offset + ray, sample)
-    MN_CHECK_ARG(cfg->use_bf16 >= 0 && cfg->use_bf16 <= 4, "use_bf16 must be 0..4 (got %d)", cfg->use_bf16);
+    MN_CHECK_ARG(cfg->use_bf16 >= 0 && cfg->use_bf16 <= MI_NERF_MODE_F16S, "use_bf16 must be 0..5 (got %d)", cfg->use_bf16);
     const int ppw = bf16_points_per_wave(cfg->use_bf16);
-    if (cfg->use_bf16) {
+    const bool f16s = cfg->use_bf16 == MI_NERF_MODE_F16S;
+    if (cfg->use_bf16 && !f16s) {
         // the bf16 kernel draws the stratified depths in its own prologue and writes z_c (one launch fewer: at a 512-ray shard a
         // launch is ~4 us of a ~130 us step)
         const StratDraw sd{cfg->near_, cfg->far_, t_rand, cfg->seed, cfg->ray_offset, z_c};
         if (int rc = mlp_rays_bf16(net, packed_c, rays, nullptr, n, Sc, raw_c, st, ppw, &sd)) return rc;
     } else {
         if (int rc = stage_stratified(n, Sc, cfg->near_, cfg->far_, t_rand, cfg->seed, cfg->ray_offset, z_c, st)) return rc;
-        if (int rc = mlp_rays_fp32(net, packed_c, rays, z_c, n, Sc, raw_c, st)) return rc;
+        if (int rc = f16s ? mlp_rays_f16s(net, packed_c, rays, z_c, n, Sc, raw_c, st) : mlp_rays_fp32(net, packed_c, rays, z_c, n, Sc, raw_c, st)) return rc;
     }
     if (cfg->Nf == 0) return stage_composite(raw_c, z_c, rays, 6, n, Sc, rgb_c, disp_c, nullptr, wts_c, nullptr, st);
     {
@@ -365,8 +383,9 @@ int mi_nerf_render_rays(const mi_nerf_net* net, const void* packed_c, const void
         float* raw_f = (float*)(w + L.raw_f);
         if (int rc = stage_composite_fine_z(raw_c, z_c, rays, n, Sc, cfg->Nf, cfg->det, u, cfg->seed, cfg->ray_offset, rgb_c, disp_c, wts_c, z_f, st))
             return rc;
-        if (int rc = cfg->use_bf16 ? mlp_rays_bf16(net, packed_f, rays, z_f, n, St, raw_f, st, ppw, nullptr)
-                                   : mlp_rays_fp32(net, packed_f, rays, z_f, n, St, raw_f, st)) return rc;
+        if (int rc = f16s ? mlp_rays_f16s(net, packed_f, rays, z_f, n, St, raw_f, st)
+                          : cfg->use_bf16 ? mlp_rays_bf16(net, packed_f, rays, z_f, n, St, raw_f, st, ppw, nullptr)
+                                          : mlp_rays_fp32(net, packed_f, rays, z_f, n, St, raw_f, st)) return rc;
         if (int rc = stage_composite(raw_f, z_f, rays, 6, n, St, rgb_f, disp_f, nullptr, nullptr, nullptr, st)) return rc;
     }
     return MI_NERF_OK;
@@ -382,7 +401,9 @@ int mi_nerf_time_mlp_rays(const mi_nerf_net* net, const void* packed, const floa
     int rc = MI_NERF_OK;
     MN_HIP(hipEventRecord(e0, st));
     for (int i = 0; i < iters && rc == MI_NERF_OK; ++i)
-        rc = use_bf16 ? mlp_rays_bf16(net, packed, rays, z, n_rays, S, raw, st, bf16_points_per_wave(use_bf16), nullptr) : mlp_rays_fp32(net, packed, rays, z, n_rays, S, raw, st);
+        rc = use_bf16 == MI_NERF_MODE_F16S ? mlp_rays_f16s(net, packed, rays, z, n_rays, S, raw, st)
+             : use_bf16 ? mlp_rays_bf16(net, packed, rays, z, n_rays, S, raw, st, bf16_points_per_wave(use_bf16), nullptr)
+                        : mlp_rays_fp32(net, packed, rays, z, n_rays, S, raw, st);
     MN_HIP(hipEventRecord(e1, st));
     MN_HIP(hipEventSynchronize(e1));
     float ms = 0.f;

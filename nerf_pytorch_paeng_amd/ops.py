@@ -29,7 +29,8 @@ def make_net(D: int, W: int, skip: int = 4, L_x: int = 10, L_d: int = 4) -> Net:
 # ------------------------------------------------------------------------------------------------
 # weights
 # ------------------------------------------------------------------------------------------------
-def pack_module(sd: Dict[str, "np.ndarray | torch.Tensor"], prefix: str, net: Net, bf16: bool = False, backward: bool = False) -> torch.Tensor:
+def pack_module(sd: Dict[str, "np.ndarray | torch.Tensor"], prefix: str, net: Net, bf16: bool = False, backward: bool = False,
+                f16s: bool = False) -> torch.Tensor:
     """Pack one NeRFModule (keys ``{prefix}linear_x.{i}.weight`` ...; model/NeRF.py:24-30) into the
     kernels' streaming layout (``backward``: the transposed stream of the backward-data kernel).
     Returns a CPU uint8 tensor; copy it to the device once."""
@@ -60,6 +61,8 @@ def pack_module(sd: Dict[str, "np.ndarray | torch.Tensor"], prefix: str, net: Ne
                  ptr(arr("linear_color.weight"), (3, W // 2)), ptr(arr("linear_color.bias"), (3,)))
     if backward:
         size_fn, pack_fn = lib().mi_nerf_packed_bytes_bwd, lib().mi_nerf_pack_weights_bwd
+    elif f16s:
+        size_fn, pack_fn = lib().mi_nerf_packed_bytes_f16s, lib().mi_nerf_pack_weights_f16s
     elif bf16:
         size_fn, pack_fn = lib().mi_nerf_packed_bytes_bf16, lib().mi_nerf_pack_weights_bf16
     else:
@@ -210,15 +213,19 @@ def mlp_embedded(net: Net, packed: torch.Tensor, x: torch.Tensor) -> torch.Tenso
     return out
 
 
-def mlp_rays(net: Net, packed: torch.Tensor, rays: torch.Tensor, z: torch.Tensor, bf16: bool = False, points_per_wave: int = 0) -> torch.Tensor:
-    """Fused encoding + MLP over rays x depths.  ``points_per_wave`` (bf16 only): 0 = launch shape chosen per launch, 64 / 32 pinned."""
+def mlp_rays(net: Net, packed: torch.Tensor, rays: torch.Tensor, z: torch.Tensor, bf16: bool = False, points_per_wave: int = 0,
+             f16s: bool = False) -> torch.Tensor:
+    """Fused encoding + MLP over rays x depths.  ``points_per_wave`` (bf16 only): 0 = launch shape chosen per launch, 64 / 32 pinned.
+    ``f16s``: the split-precision variant (fp32-grade results on the f16 matrix pipe; ``packed`` from pack_module(..., f16s=True))."""
     n, S = z.shape
     if tuple(rays.shape) != (n, 6):
         raise MiNerfError(f"rays must be [n,6], got {tuple(rays.shape)}")
     raw = torch.empty(n, S, 4, dtype=torch.float32, device=z.device)
     args = (C.byref(net), dev_ptr(packed, "packed", torch.uint8, 16), dev_ptr(rays, "rays"), dev_ptr(z, "z"), n, S, dev_ptr(raw, "raw", align=16))
     with _guard(z.device):
-        if bf16:
+        if f16s:
+            check(lib().mi_nerf_mlp_rays_f16s(*args, stream_ptr(z.device)), "mi_nerf_mlp_rays_f16s")
+        elif bf16:
             check(lib().mi_nerf_mlp_rays_bf16_shape(*args, int(points_per_wave), stream_ptr(z.device)), "mi_nerf_mlp_rays_bf16_shape")
         else:
             check(lib().mi_nerf_mlp_rays(*args, stream_ptr(z.device)), "mi_nerf_mlp_rays")
@@ -553,14 +560,18 @@ def permute_rows(src: torch.Tensor, perm: torch.Tensor) -> torch.Tensor:
 # fused render
 # ------------------------------------------------------------------------------------------------
 BF16_SHAPES = {0: 1, 64: 2, 32: 3, 832: 4}          # points per wave (832: 8 waves of 32 per workgroup) -> mi_nerf_render_cfg.use_bf16
+MODE_F16S = 5                                       # mi_nerf_render_cfg.use_bf16 for the f16 split-precision variant
 
 
 def render_cfg(near: float, far: float, Sc: int, Nf: int, det: bool, bf16: bool = False, points_per_wave: int = 0, seed: int = 0,
-               ray_offset: int = 0) -> RenderCfg:
+               ray_offset: int = 0, f16s: bool = False) -> RenderCfg:
     """``points_per_wave`` (bf16 only): 0 = the bf16 kernel's launch shape is chosen per launch; 64 / 32 pin it.
+    ``f16s``: the split-precision MLP variant (blobs from PackedNeRF.f16s()).
     ``seed`` / ``ray_offset`` key the jitter the kernels draw themselves when render_rays gets no ``t_rand`` / ``u`` tensor."""
-    return RenderCfg(float(near), float(far), int(Sc), int(Nf), int(bool(det)), BF16_SHAPES[int(points_per_wave)] if bf16 else 0,
-                     int(seed) & 0xFFFFFFFF, 0, int(ray_offset))
+    if bf16 and f16s:
+        raise MiNerfError("bf16 and f16s are different precision modes: pick one")
+    mode = MODE_F16S if f16s else (BF16_SHAPES[int(points_per_wave)] if bf16 else 0)
+    return RenderCfg(float(near), float(far), int(Sc), int(Nf), int(bool(det)), mode, int(seed) & 0xFFFFFFFF, 0, int(ray_offset))
 
 
 def workspace_layout(cfg: RenderCfg, n: int) -> WorkspaceLayout:
@@ -614,13 +625,13 @@ def workspace_views(cfg: RenderCfg, n: int, workspace: torch.Tensor) -> Dict[str
 
 
 def time_mlp_rays(net: Net, packed: torch.Tensor, rays: torch.Tensor, z: torch.Tensor, raw: torch.Tensor, iters: int, bf16: bool = False,
-                  points_per_wave: int = 0) -> float:
+                  points_per_wave: int = 0, f16s: bool = False) -> float:
     """Average device milliseconds per fused-MLP launch, from hipEvents on the launch stream."""
     n, S = z.shape
     ms = C.c_float(0.0)
     with _guard(z.device):
         check(lib().mi_nerf_time_mlp_rays(C.byref(net), dev_ptr(packed, "packed", torch.uint8, 16), dev_ptr(rays, "rays"), dev_ptr(z, "z"), n, S,
-                                          dev_ptr(raw, "raw", align=16), iters, BF16_SHAPES[int(points_per_wave)] if bf16 else 0, C.byref(ms),
+                                          dev_ptr(raw, "raw", align=16), iters, MODE_F16S if f16s else (BF16_SHAPES[int(points_per_wave)] if bf16 else 0), C.byref(ms),
                                           stream_ptr(z.device)), "mi_nerf_time_mlp_rays")
     return float(ms.value)
 

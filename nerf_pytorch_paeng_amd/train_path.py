@@ -21,7 +21,7 @@ import torch
 
 from . import ops
 from ._lib import MiNerfError, Net, as_f32_dev
-from .weights import infer_net
+from .weights import _param_shape, infer_net
 
 # rays per autograd node: the activation stash is ~9.9 KB per sample point (W = 256, D = 8)
 MAX_TRAIN_RAYS = 16384
@@ -154,18 +154,6 @@ class _EmbeddedTrain(torch.autograd.Function):
             out.append(grads[off:off + cnt].view(shape))
             off += cnt
         return (None, None, *out)
-
-
-def _param_shape(net: Net, key: str) -> Tuple[int, ...]:
-    W, in_x, in_d = net.W, 3 + 6 * net.L_x, 3 + 6 * net.L_d
-    mod, kind = key.rsplit(".", 1)
-    if mod.startswith("linear_x."):
-        l = int(mod.split(".")[1])
-        fan_in = in_x if l == 0 else (W + in_x if (net.skip >= 0 and l == net.skip + 1) else W)
-        out = W
-    else:
-        out, fan_in = {"linear_d": (W // 2, W + in_d), "linear_feat": (W, W), "linear_density": (1, W), "linear_color": (3, W // 2)}[mod]
-    return (out, fan_in) if kind == "weight" else (out,)
 
 
 def render_train(rays: torch.Tensor, model: torch.nn.Module, opts, *, t_rand=None, u=None, seed: int = 0, ray_offset: int = 0,

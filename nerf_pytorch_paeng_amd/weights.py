@@ -42,12 +42,26 @@ def infer_net(sd: Dict[str, "np.ndarray | torch.Tensor"], prefix: str = "model_c
     return ops.make_net(D, W, skip, (in_x - 3) // 6, (in_d - 3) // 6)
 
 
+def _param_shape(net: Net, key: str) -> Tuple[int, ...]:
+    """Shape of one parameter of a NeRFModule (model/NeRF.py:24-30) from the network description."""
+    W, in_x, in_d = net.W, 3 + 6 * net.L_x, 3 + 6 * net.L_d
+    mod, kind = key.rsplit(".", 1)
+    if mod.startswith("linear_x."):
+        l = int(mod.split(".")[1])
+        fan_in = in_x if l == 0 else (W + in_x if (net.skip >= 0 and l == net.skip + 1) else W)
+        out = W
+    else:
+        out, fan_in = {"linear_d": (W // 2, W + in_d), "linear_feat": (W, W), "linear_density": (1, W), "linear_color": (3, W // 2)}[mod]
+    return (out, fan_in) if kind == "weight" else (out,)
+
+
 class PackedNeRF:
     """Both networks of a NeRF, packed and resident on one device."""
 
     def __init__(self, net: Net, coarse: torch.Tensor, fine: torch.Tensor):
         self.net, self.coarse, self.fine = net, coarse, fine
         self._bf16: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
+        self._f16s: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
         self._sd = None
         self._flat: Optional[Tuple[torch.Tensor, torch.Tensor]] = None      # device-resident flat parameter vectors (nn.Module source)
 
@@ -85,6 +99,27 @@ class PackedNeRF:
                 self._bf16 = (ops.pack_module(self._sd, "model_coarse.", self.net, bf16=True).to(self.device),
                               ops.pack_module(self._sd, "model_fine.", self.net, bf16=True).to(self.device))
         return self._bf16
+
+    def f16s(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Blobs of the split-precision variant (weights as f16 hi + lo pairs), packed lazily on the host: from the kept state dict, or
+        -- a PackedNeRF made from an nn.Module -- from its flat parameter vectors (one device -> host copy per packed_for() call: pass
+        a PackedNeRF to render many batches from frozen weights)."""
+        if self._f16s is None:
+            sd = self._sd
+            if sd is None:
+                if self._flat is None:
+                    raise MiNerfError("f16-split packing needs the state dict (keep_state=True)")
+                sd = {}
+                for prefix, flat in zip(("model_coarse.", "model_fine."), self._flat):
+                    host, off = flat.detach().cpu().numpy(), 0
+                    for name in ops.param_names(self.net):
+                        shape = _param_shape(self.net, name)
+                        cnt = int(np.prod(shape))
+                        sd[prefix + name] = host[off:off + cnt].reshape(shape)
+                        off += cnt
+            self._f16s = (ops.pack_module(sd, "model_coarse.", self.net, f16s=True).to(self.device),
+                          ops.pack_module(sd, "model_fine.", self.net, f16s=True).to(self.device))
+        return self._f16s
 
     def blob(self, is_fine: bool) -> torch.Tensor:
         return self.fine if is_fine else self.coarse

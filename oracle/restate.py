@@ -269,6 +269,50 @@ def mlp_forward_bf16(sd: Dict[str, torch.Tensor], prefix: str, x: torch.Tensor, 
     return torch.cat([rgb, sigma], -1)
 
 
+def f16_split(t: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """t = hi + lo with hi = f16(t) and lo = f16((t - hi) * 2^11) * 2^-11, both returned as fp32 (the operand format of the
+    split-precision MFMA variant, nerf_pytorch_paeng_amd/csrc/mlp_f16s.hip)."""
+    t = t.to(F32)
+    hi = t.to(torch.float16).to(F32)
+    lo = ((t - hi) * 2048.0).to(torch.float16).to(F32) / 2048.0
+    return hi, lo
+
+
+def mlp_forward_f16split(sd: Dict[str, torch.Tensor], prefix: str, x: torch.Tensor, D: int, in_x: int, in_d: int,
+                         skips: Sequence[int] = (4,), dtype=torch.float64) -> torch.Tensor:
+    """``mlp_forward`` with the ROUNDING POINTS of the split-precision variant (mlp_f16s.hip): every weight, every encoded input and
+    every activation (after ReLU; linear_feat's output without) is carried as an f16 pair hi + lo, a product is hi.hi + hi.lo + lo.hi
+    (lo.lo dropped); the view-direction columns of linear_d are folded into a per-ray fp32 bias and not split.  Partial products are
+    accumulated in ``dtype`` (fp64 by default: what is left against the kernel is its fp32 summation order).  The network is
+    model/NeRF.py:33-52 unchanged; the result is expected to be as close to an fp64 evaluation as the reference's own fp32 arithmetic."""
+    def split_lin(name, v, cols=None):
+        w = torch.as_tensor(sd[f"{prefix}{name}.weight"]).float()
+        b = torch.as_tensor(sd[f"{prefix}{name}.bias"]).to(dtype)
+        if cols is not None:
+            w_rest = torch.cat([w[:, :cols.start], w[:, cols.stop:]], -1).to(dtype)
+            w = w[:, cols]
+        wh, wl = (t.to(dtype) for t in f16_split(w))
+        vs = v if cols is None else v[:, cols]
+        vh, vl = (t.to(dtype) for t in f16_split(vs))
+        out = vh @ wh.T + (vl @ wh.T + vh @ wl.T) + b
+        if cols is not None:
+            out = out + torch.cat([v[:, :cols.start], v[:, cols.stop:]], -1).to(dtype) @ w_rest.T
+        return out.to(F32)                       # the kernel combines acc_hi + acc_lo * 2^-11 in fp32 before it splits again
+    x = x.to(F32)
+    gx, gd = x[:, :in_x], x[:, in_x:in_x + in_d]
+    h = gx
+    for i in range(D):
+        h = torch.relu(split_lin(f"linear_x.{i}", h))
+        if i in skips:
+            h = torch.cat([gx, h], -1)
+    W = torch.as_tensor(sd[f"{prefix}linear_feat.weight"]).shape[0]
+    sigma = split_lin("linear_density", h)
+    feat = split_lin("linear_feat", h)
+    g = torch.relu(split_lin("linear_d", torch.cat([feat, gd], -1), slice(0, W)))
+    rgb = split_lin("linear_color", g)
+    return torch.cat([rgb, sigma], -1)
+
+
 def run_network(sd, x: torch.Tensor, cfg: PathConfig, is_fine: bool, chunk: Optional[int] = None,
                 dtype=F32) -> torch.Tensor:
     """Chunked evaluation (nerf_process.py:190-192,206-207; NeRF.py:70-78)."""

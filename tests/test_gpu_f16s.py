@@ -1,0 +1,133 @@
+"""The split-precision variant (csrc/mlp_f16s.hip): fp32-grade results on the f16 matrix pipe.
+
+Weights and activations travel as f16 pairs x = hi + lo * 2^-11; a product is three v_mfma_f32_16x16x32_f16 with fp32 accumulation.
+It is held to the bars of the fp32 path itself (tests/test_gpu_parity.py): raw network outputs against an fp64 evaluation within
+4x the distance of the reference's own fp32 arithmetic, rendered colours against the CPU oracle within 2e-5 with pinned depths, at
+most 1 % of un-pinned rays off by more than 1e-4 -- and, tightly, to the oracle restatement with the same rounding points
+(R.mlp_forward_f16split), which a packing or ordering error cannot pass."""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from nerf_pytorch_paeng_amd import nerf_process as NP
+from nerf_pytorch_paeng_amd import ops, synthetic, weights
+from nerf_pytorch_paeng_amd._lib import MiNerfError
+from oracle import restate as R
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+T = torch.from_numpy
+
+
+def make_opts(**kw):
+    base = dict(near=2.0, far=6.0, N_samples_c=64, N_samples_f=128, perturb=1.0, chunk_rays=4096, chunk_pts=524288,
+                data_type="blender", gpu_ids=[0], rank=0)
+    base.update(kw)
+    return SimpleNamespace(**base)
+
+
+@pytest.fixture(scope="module")
+def lego_rays():
+    K, H, W = synthetic.lego_camera()
+    pix = T(synthetic.pixel_batch(H, W, 4096, 0)).to(DEV)
+    o, d = ops.make_o_d_pixels(W, H, K, synthetic.pose_spherical(0.0, -30.0, 4.0), pix)
+    return torch.cat([o, d], -1).contiguous()
+
+
+@pytest.fixture(scope="module")
+def packed_big():
+    return weights.PackedNeRF.from_state_dict(synthetic.make_state_dict(0, 8, 256), DEV)
+
+
+@pytest.mark.parametrize("D,skip,L_x,L_d,n,S", [(8, 4, 10, 4, 64, 192), (8, 4, 10, 4, 33, 100), (8, 4, 10, 4, 5, 64), (8, 4, 10, 4, 700, 33),
+                                                 (7, 5, 10, 4, 37, 96), (3, -1, 10, 4, 37, 96), (8, 3, 10, 4, 37, 96), (2, -1, 10, 4, 37, 96),
+                                                 (9, 0, 10, 4, 37, 96), (8, 4, 6, 2, 37, 96), (4, -1, 0, 4, 37, 96)])
+def test_f16s_mlp_vs_oracles(D, skip, L_x, L_d, n, S, lego_rays):
+    """Raw network outputs of the split-precision kernel: (1) against the restatement with its rounding points (fp64 accumulation):
+    what is left is fp32 summation order; (2) against the fp64 evaluation of the network: no further than 4x the reference's own fp32
+    arithmetic (and than the fp32 MFMA kernel).  Both trunk polarities, the skip layer at odd / even l, no skip, fewer frequencies,
+    ragged sample counts, flat and ray-major tile walks."""
+    skips = (skip,) if skip >= 0 else ()
+    in_x, in_d = 3 + 6 * L_x, 3 + 6 * L_d
+    sd = synthetic.make_state_dict(17 + D + L_x, D, 256, in_x=in_x, in_d=in_d, skips=skips)
+    packed = weights.PackedNeRF.from_state_dict(sd, DEV)
+    rays = lego_rays[:n].contiguous()
+    z = torch.sort(T(R.counter_uniform(3, 0, 0, n, S)) * 4 + 2, -1)[0]
+    x = R.embed(rays.cpu(), z, L_x, L_d)
+    ref64 = R.mlp_forward(sd, "model_fine.", x.double(), D, in_x, in_d, skips=skips, dtype=torch.float64)
+    ref32 = R.mlp_forward(sd, "model_fine.", x, D, in_x, in_d, skips=skips)
+    emu = R.mlp_forward_f16split(sd, "model_fine.", x, D, in_x, in_d, skips=skips)
+    got = ops.mlp_rays(packed.net, packed.f16s()[1], rays, z.to(DEV), f16s=True).cpu().reshape(-1, 4)
+    fp32k = ops.mlp_rays(packed.net, packed.fine, rays, z.to(DEV)).cpu().reshape(-1, 4)
+    assert torch.isfinite(got).all()
+    e_emu = float((got.double() - emu.double()).abs().max())
+    e64 = float((got.double() - ref64).abs().max())
+    e_ref = float((ref32.double() - ref64).abs().max())
+    e_k32 = float((fp32k.double() - ref64).abs().max())
+    print(f"f16s D={D} skip={skip} L={L_x}/{L_d} n={n} S={S}: vs its restatement {e_emu:.2e}; vs fp64 {e64:.2e} (reference fp32 {e_ref:.2e}, fp32 kernel {e_k32:.2e})")
+    # gamma(x) is evaluated by the kernel (sin / cos of arguments up to 3e3 rad) and by torch on the oracle side: the encoded inputs
+    # differ by a few 1e-7, which the network amplifies alike for every implementation
+    assert e_emu <= 3e-5, e_emu
+    assert e64 <= 4.0 * max(e_ref, e_k32) + 1e-6, (e64, e_ref, e_k32)
+
+
+def test_f16s_config2_all_rays_vs_oracle(packed_big, lego_rays):
+    """BASELINE config #2 at full size through the split-precision variant, EVERY ray against the CPU oracle, to the bars the fp32
+    path is held to (test_config2_all_rays_vs_oracle): coarse colours and disparities directly; fine outputs with the depths pinned to
+    the ones the HIP path sampled; un-pinned rays more than 1e-4 off: at most 1 %."""
+    opts = make_opts()
+    a = NP.render_rays(lego_rays, packed_big, None, opts, seed=11, return_intermediates=True, f16s=True)
+    b = NP.render_rays(lego_rays, packed_big, None, opts, seed=11, return_intermediates=True)
+    sd = synthetic.make_state_dict(0, 8, 256)
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    rc, tr, uu = lego_rays.cpu(), a["_t_rand"].cpu(), a["_u"].cpu()
+    with torch.no_grad():
+        ref = R.render_rays(rc, sd, R.PathConfig(), tr, uu)
+        pin = R.render_rays(rc, sd, R.PathConfig(), tr, uu, z_fine_override=a["_z_f"].cpu())
+    e_c = float((a["rgb_c"].cpu() - ref["rgb_c"]).abs().max())
+    e_dc = float((a["disp_c"].cpu() - ref["disp_c"]).abs().max())
+    e_f = float((a["rgb_f"].cpu() - pin["rgb_f"]).abs().max())
+    bad = float(((a["rgb_f"].cpu() - ref["rgb_f"]).abs().max(-1)[0] > 1e-4).float().mean())
+    mse = float(((a["rgb_f"].cpu() - ref["rgb_f"]) ** 2).mean())
+    mse32 = float(((a["rgb_f"] - b["rgb_f"]) ** 2).mean())
+    print(f"f16s config #2, 4096 rays vs oracle: rgb_c {e_c:.2e}, disp_c {e_dc:.2e}; pinned rgb_f {e_f:.2e}; un-pinned rays off by >1e-4: {bad:.4f}, "
+          f"PSNR vs oracle {R.mse2psnr(mse):.1f} dB, vs the fp32 HIP path {R.mse2psnr(max(mse32, 1e-30)):.1f} dB")
+    assert e_c <= 2e-5 and e_dc <= 2e-4, (e_c, e_dc)
+    assert e_f <= 2e-5, e_f
+    assert bad <= 0.01 and R.mse2psnr(mse) > 90.0, (bad, R.mse2psnr(mse))
+
+
+def test_f16s_surface(packed_big, lego_rays):
+    """Chunk / shard invariance, the frame path, module models, refusals."""
+    from nerf_pytorch_paeng_amd import dist as mdist
+    from nerf_pytorch_paeng_amd.model import NeRF
+    opts = make_opts(N_samples_c=32, N_samples_f=32)
+    rays = lego_rays[:300].contiguous()
+    whole = NP.render_rays(rays, packed_big, None, opts, seed=5, f16s=True)
+    part = NP.render_rays(rays[100:250].contiguous(), packed_big, None, opts, seed=5, ray_offset=100, f16s=True)
+    assert torch.equal(part["rgb_f"], whole["rgb_f"][100:250])
+    K, H, W = synthetic.lego_camera()
+    s = 24.0 / W
+    Ks = K.copy(); Ks[0, 0] *= s; Ks[1, 1] *= s; Ks[0, 2] = 12.0; Ks[1, 2] = 10.0
+    pose = synthetic.pose_spherical(30.0, -30.0, 4.0)
+    rgb, disp = mdist.render_frame(20, 24, Ks, pose, packed_big, opts, seed=5, f16s=True)
+    rgb32, _ = mdist.render_frame(20, 24, Ks, pose, packed_big, opts, seed=5)
+    assert rgb.shape == (20, 24, 3) and float((rgb - rgb32).abs().max()) < 5e-3          # a sample_pdf bin flip at worst
+    sd = synthetic.make_state_dict(0, 8, 256)
+    model = NeRF(8, 256, 63, 27).to(DEV)
+    model.load_state_dict({k: T(v) for k, v in sd.items()})
+    with torch.no_grad():
+        m = NP.render_rays(rays, model, None, opts, seed=5, f16s=True)
+    assert torch.equal(m["rgb_f"], whole["rgb_f"])
+    with pytest.raises(MiNerfError):
+        NP.render_rays(rays, packed_big, None, opts, seed=5, f16s=True, bf16=True)
+    with pytest.raises(MiNerfError):                                                        # W = 128: not built for this variant
+        weights.PackedNeRF.from_state_dict(synthetic.make_state_dict(1, 4, 128), DEV).f16s()
+    big = synthetic.make_state_dict(0, 8, 256)
+    big["model_fine.linear_feat.weight"] = big["model_fine.linear_feat.weight"].copy()
+    big["model_fine.linear_feat.weight"][3, 5] = 7.0e4                                      # beyond the f16 range: refused, not clipped
+    with pytest.raises(MiNerfError):
+        weights.PackedNeRF.from_state_dict(big, DEV).f16s()
