@@ -255,6 +255,9 @@ __device__ __forceinline__ void dma16(const char* gaddr_lane) {
     asm volatile("global_load_lds_dwordx4 %0, off offset:%1" ::"v"(gaddr_lane), "i"(IMM) : "memory");
 }
 __device__ __forceinline__ void ring_dma(const Ring& r, int i) {
+#ifdef MN_F16S_NODMA                                          // ablation builds (timing experiments only, results are garbage)
+    return;
+#endif
     const char* g = r.sbase + r.fetch_off + r.voff + (i >= 4 ? 4096 : 0);
     if (i == 0) set_m0(r.fetch_lds);
     if (i == 4) set_m0(r.fetch_lds + 4096);

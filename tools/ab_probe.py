@@ -13,10 +13,11 @@ from nerf_pytorch_paeng_amd import _lib, ops, synthetic, weights
 tag = sys.argv[1]
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 bf16 = len(sys.argv) > 3 and sys.argv[3] == "bf16"
+f16s = len(sys.argv) > 3 and sys.argv[3] == "f16s"           # the split-precision variant
 ppw = int(sys.argv[4]) if len(sys.argv) > 4 else 0           # bf16 launch shape: 0 = the launcher's choice, 64 / 32 pinned
 N = int(sys.argv[5]) if len(sys.argv) > 5 else 4096
 S = int(sys.argv[6]) if len(sys.argv) > 6 else 192
-use_bf16 = {0: 1, 64: 2, 32: 3}[ppw] if bf16 else 0
+use_bf16 = 5 if f16s else ({0: 1, 64: 2, 32: 3}[ppw] if bf16 else 0)
 dev = torch.device("cuda:0")
 packed = weights.PackedNeRF.from_state_dict(synthetic.make_state_dict(0, 8, 256), dev)
 K, H, W = synthetic.lego_camera()
@@ -37,7 +38,7 @@ for tg in tag.split(","):
 
 def time(lib, iters=20):
     ms = C.c_float(0.0)
-    blob = packed.bf16()[1] if bf16 else packed.fine
+    blob = packed.f16s()[1] if f16s else (packed.bf16()[1] if bf16 else packed.fine)
     rc = lib.mi_nerf_time_mlp_rays(C.byref(packed.net), blob.data_ptr(), rays.data_ptr(), z.data_ptr(), N, S, raw.data_ptr(), iters, use_bf16,
                                    C.byref(ms), torch.cuda.current_stream(dev).cuda_stream)
     assert rc == 0
