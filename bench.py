@@ -20,7 +20,8 @@ the same run for N > 1; at N = 1 the two are the same measurement.
 Also on the line: the 800x800 frame time (rows sharded over the ranks, ONE all-gather of the output tiles
 over RCCL), `roofline` for the dominant kernel (the fine-network fused MLP launch, hipEvent-timed on its
 launch stream), `bf16` (BASELINE config #5: the same step on the bf16 MFMA variant with its PSNR against the
-fp32 outputs of the same rays, and its own `small_batch`), `small_batch` (the same step at 256..2048 rays on
+fp32 outputs of the same rays, and its own `small_batch`), `f16_split` (the split-precision variant: f16 hi + lo
+operands on the f16 matrix pipe, fp32-grade results; an extra leg, never `value`), `small_batch` (the same step at 256..2048 rays on
 one GPU: what a rank sees under strong scaling) and `cpu_baseline` (the CPU oracle timed on the host cores;
 rank 0, N = 1 only).
 
@@ -36,6 +37,7 @@ from __future__ import annotations
 import argparse
 import hashlib
 import json
+import math
 import os
 import socket
 import subprocess
@@ -78,6 +80,7 @@ def parse():
                     help="strong: the 4096-ray batch sharded over the GPUs (value); weak: 4096 rays per GPU (value_weak); both (default)")
     ap.add_argument("--no-small-batch", action="store_true", help="skip the 256..2048-ray legs (N = 1)")
     ap.add_argument("--no-bf16-leg", action="store_true", help="skip the bf16 leg (BASELINE config #5) of the default fp32 run")
+    ap.add_argument("--no-f16s-leg", action="store_true", help="skip the split-precision (f16 hi + lo operands, fp32-grade results) leg of the default fp32 run")
     return ap.parse_args()
 
 
@@ -334,6 +337,53 @@ def worker(args) -> None:
                     "max_abs_rgb_f_diff": round(float((out16[2] - ref32[2]).abs().max()), 5)}
         del raw16, zf16
 
+    # ---- the split-precision variant (mlp_f16s.hip): fp32-grade results on the f16 matrix pipe.  An EXTRA leg: `value` and `roofline`
+    # above stay the fp32-MFMA kernel's, this one is reported against both peaks with its own dtype name ----
+    f16s_leg = None
+    if not args.bf16 and not args.no_f16s_leg:
+        blobs_s = packed.f16s()
+        out_s = tuple(torch.empty_like(t) for t in main.out)
+        cfg_s = ops.render_cfg(opts.near, opts.far, SC, NF, False, seed=0, ray_offset=main.first, f16s=True)
+
+        def step_s():
+            ops.render_rays(packed.net, blobs_s[0], blobs_s[1], cfg_s, main.rays, None, None, workspace=main.ws, out=out_s)
+
+        step(main)
+        ref32 = tuple(t.clone() for t in main.out)
+        for _ in range(args.warmup):
+            step_s()
+        torch.cuda.synchronize(dev)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step_s()
+        torch.cuda.synchronize(dev)
+        barrier()
+        el_s = max_over_ranks(time.perf_counter() - t0)
+        zf_s = ops.workspace_views(cfg_s, main.n, main.ws)["z_f"].clone()
+        raw_s = torch.empty(main.n, SC + NF, 4, device=dev)
+        ops.time_mlp_rays(packed.net, blobs_s[1], main.rays, zf_s, raw_s, 2, f16s=True)
+        ks = ops.time_mlp_rays(packed.net, blobs_s[1], main.rays, zf_s, raw_s, iters, f16s=True)
+        net_tf = k_flop / (ks * 1e-3) / 1e12
+        n_total = N_RAYS if headline_strong else world * N_RAYS
+        mse = float(torch.mean((out_s[2] - ref32[2]) ** 2))
+        f16s_leg = {"what": "the same step with every operand split x = hi + lo 2^-11 into two f16 values and every product taken as hi hi + hi lo + lo hi on "
+                            "v_mfma_f32_16x16x32_f16 (fp32 accumulate): fp32-grade results (tests/test_gpu_f16s.py holds it to the fp32 path's parity bars); "
+                            "this run's shard and jitter; an extra leg, never the headline",
+                    "dtype": "f16 hi+lo split operands, f32 accumulate",
+                    "rays_per_s": round(n_total * args.steps / el_s, 1), "ms_per_step": round(1e3 * el_s / args.steps, 4),
+                    "fine_kernel_ms": round(ks, 4),
+                    "network_TFLOPs": round(net_tf, 1),                                 # the network's arithmetic (what the fp32 kernel's 149 counts)
+                    "x_f32_mfma_peak": round(net_tf / PEAK_F32_MFMA_TFLOPS, 3),
+                    "issued_f16_mfma_TFLOPs": round(3 * net_tf, 1),                       # three f16 MFMAs per product
+                    "issued_frac_of_f16_peak": round(3 * net_tf / PEAK_BF16_MFMA_TFLOPS, 4),  # dense f16 peak = dense bf16 peak (2.5 PF)
+                    "speedup_vs_f32_step": round(ms_strong / (1e3 * el_s / args.steps), 3) if headline_strong else None,
+                    "max_abs_rgb_c_diff_vs_f32": float((out_s[0] - ref32[0]).abs().max()),
+                    "max_abs_rgb_f_diff_vs_f32": float((out_s[2] - ref32[2]).abs().max()),
+                    "rays_beyond_1e-4_rgb_f": int(((out_s[2] - ref32[2]).abs().amax(-1) > 1e-4).sum()),
+                    "psnr_rgb_f_vs_fp32_dB": round(-10.0 * math.log10(max(mse, 1e-20)), 2)}
+        del raw_s, zf_s
+
     # ---- the same step at small batches (one GPU): what a rank runs under strong scaling ---------------------------
     def small_batch_legs(step_fn, cfg_, blob_fine, is_bf16: bool, peak_tflops: float):
         legs = []
@@ -538,6 +588,8 @@ def worker(args) -> None:
             line["frac_of_f32_mfma_roofline_end_to_end"] = line["frac_of_roofline_end_to_end"]
         if bf16_leg is not None:
             line["bf16"] = bf16_leg
+        if f16s_leg is not None:
+            line["f16_split"] = f16s_leg
         if small is not None:
             line["small_batch"] = small
         if train is not None:
