@@ -12,7 +12,7 @@ REQUIRED = {"metric": str, "value": (int, float), "unit": str, "n_gpus": int, "s
 
 @pytest.mark.parametrize("name", ["r02_bench_n1.json", "r02_bench_n1_bf16.json", "r02_bench_n1_fern.json", "r02_bench_n2_gloo_rehearsal.json",
                                   "r03_bench_n1.json", "r03_bench_n1_bf16.json", "r03_bench_n1_fern.json", "r03_bench_n4_gloo_rehearsal.json",
-                                  "r03_bench_rank3_of_8_alone.json"])
+                                  "r03_bench_rank3_of_8_alone.json", "r03_bench_n1_with_f16_split.json"])
 def test_committed_bench_line_has_the_contract_fields(name):
     path = os.path.join(ROOT, "profiles", name)
     with open(path) as f:
@@ -34,6 +34,12 @@ def test_committed_bench_line_has_the_contract_fields(name):
         assert [l["rays"] for l in line["bf16"]["small_batch"]] == [256, 512, 1024, 2048]
         assert {"wgrad_256x256", "wgrad_9x256x256"} <= set(line["train"])
         assert line["roofline"]["traffic_is_current"] is True
+    if name == "r03_bench_n1_with_f16_split.json":        # the split-precision step is an EXTRA leg: the headline stays the fp32-MFMA kernel's
+        leg = line["f16_split"]
+        assert line["dtype"] == "f32" and "mlp_fp32_kernel" in roof["kernel"] and roof["peak"] == 157.3
+        assert "f16" in leg["dtype"] and leg["rays_per_s"] > 2 * line["value"]
+        assert abs(leg["issued_f16_mfma_TFLOPs"] - 3 * leg["network_TFLOPs"]) < 0.5
+        assert leg["max_abs_rgb_c_diff_vs_f32"] < 2e-6 and leg["rays_beyond_1e-4_rgb_f"] < 0.005 * 4096
     if line["n_gpus"] == 1 and "cpu_baseline" in line:
         cpu = line["cpu_baseline"]
         for key in ("value", "unit", "cores", "kind", "sample"):

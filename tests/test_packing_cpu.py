@@ -225,14 +225,15 @@ def test_bf16_pack_map_reproduces_the_host_blob(D, skip):
     assert np.array_equal(src[sb // 2:], want_side)
 
 
-def test_bf16_kernel_owns_m0_and_the_agpr_file():
-    """mlp_bf16.hip sets M0 without saving it and addresses the whole AGPR file by explicit register numbers: both are only
-    sound while hipcc itself never touches M0 / an AGPR in that kernel.  Disassemble the object and check."""
+@pytest.mark.parametrize("src,mfma_name,min_mfma", [("mlp_bf16.hip", "v_mfma_f32_16x16x32_bf16", 4000), ("mlp_f16s.hip", "v_mfma_f32_16x16x32_f16", 6000)])
+def test_fragment_file_kernels_own_m0_and_the_agpr_file(src, mfma_name, min_mfma):
+    """mlp_bf16.hip and mlp_f16s.hip set M0 without saving it and address the whole AGPR file by explicit register numbers: both are only
+    sound while hipcc itself never touches M0 / an AGPR in those kernels.  Disassemble the objects and check."""
     import os
     import re
     import subprocess
     from nerf_pytorch_paeng_amd import build
-    obj = os.path.join(build.CSRC, "build", "mlp_bf16.hip.o")
+    obj = os.path.join(build.CSRC, "build", src + ".o")
     assert os.path.exists(obj), "build the library first"
     objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
     if not os.path.exists(objdump):
@@ -250,12 +251,12 @@ def test_bf16_kernel_owns_m0_and_the_agpr_file():
     finally:
         shutil.rmtree(work)
     lines = [l.split("//")[0].strip() for l in asm.splitlines()]
-    mfma = [l for l in lines if l.startswith("v_mfma_f32_16x16x32_bf16")]
-    assert len(mfma) > 4000
+    mfma = [l for l in lines if l.startswith(mfma_name)]
+    assert len(mfma) > min_mfma
     assert not any(l.startswith("v_accvgpr_read") for l in lines)                 # the compiler never moves data out of the file
     assert not any(l.startswith("scratch_") for l in lines)                       # no spills
     m0 = [l for l in lines if re.search(r"\bm0\b", l)]
     assert m0 and all(re.fullmatch(r"s_mov_b32 m0, s\d+", l) for l in m0), m0[:5]  # only our "s_mov_b32 m0, sN"
     for l in lines:                                                               # AGPRs appear only as MFMA B operands / accvgpr_write targets
         if re.search(r"\ba\[?\d", l):
-            assert l.startswith("v_accvgpr_write_b32 a") or l.startswith("v_mfma_f32_16x16x32_bf16 v["), l
+            assert l.startswith("v_accvgpr_write_b32 a") or l.startswith(mfma_name + " v["), l
