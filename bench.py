@@ -439,6 +439,19 @@ def worker(args) -> None:
         barrier()
         frame_ms = 1e3 * max_over_ranks(time.perf_counter() - t0) / args.frames
         assert (rgb.shape == (H, W, 3) or solo) and torch.isfinite(rgb).all()
+        if f16s_leg is not None and not solo:                           # the same frame(s) in split precision, held against the fp32 frame just rendered
+            mdist.render_frame(H, W, K, pose, packed, opts, seed=0, f16s=True)
+            torch.cuda.synchronize(dev)
+            barrier()
+            t0 = time.perf_counter()
+            for f in range(args.frames):
+                fpose = synthetic.fern_pose() if fern else synthetic.pose_spherical(3.0 * (f + 1), -30.0, 4.0)
+                rgb_s, _ = mdist.render_frame(H, W, K, fpose, packed, opts, seed=0, f16s=True)
+            torch.cuda.synchronize(dev)
+            barrier()
+            f16s_leg["frame_ms"] = round(1e3 * max_over_ranks(time.perf_counter() - t0) / args.frames, 2)
+            f16s_leg["frame_psnr_vs_f32_dB"] = round(-10.0 * math.log10(max(float(torch.mean((rgb_s - rgb) ** 2)), 1e-20)), 2)
+            f16s_leg["frame_pixels_beyond_1_grey_level"] = int(((rgb_s - rgb).abs().amax(-1) > 1.0 / 255.0).sum())
 
     # ---- training step: forward + backward + Adam on this rank's 4096-ray batch --------------
     train = None
