@@ -195,10 +195,19 @@ def llff_cameras(raw_poses, raw_bds, bd_factor=.75, path_zflat: bool = False) ->
 # ---------------------------------------------------------------------------------------------------
 # eval / video harness
 # ---------------------------------------------------------------------------------------------------
+def _precision(opts) -> Dict[str, bool]:
+    """``opts.precision`` (not a flag of the reference's config.py; absent = "fp32", the reference's arithmetic) selects the network's
+    precision mode for the eval / video harness: "fp32" | "f16s" (split precision: fp32-grade results, ~3x faster) | "bf16"."""
+    mode = str(getattr(opts, "precision", "fp32")).lower()
+    if mode not in ("fp32", "f16s", "bf16"):
+        raise ValueError(f"opts.precision must be 'fp32', 'f16s' or 'bf16', got {mode!r}")
+    return {"bf16": mode == "bf16", "f16s": mode == "f16s"}
+
+
 def _render_pose(model, posenc, K, pose, hw, opts):
     img_h, img_w = hw
     rays_o, rays_d = make_o_d(img_w, img_h, K, pose[:3, :4])
-    rgb_c, disp_c, rgb_f, disp_f = NP.batchify_rays_and_render_by_chunk(rays_o, rays_d, model, posenc, img_h, img_w, K, opts)
+    rgb_c, disp_c, rgb_f, disp_f = NP.batchify_rays_and_render_by_chunk(rays_o, rays_d, model, posenc, img_h, img_w, K, opts, **_precision(opts))
     return (rgb_c, disp_c) if int(opts.N_samples_f) == 0 else (rgb_f, disp_f)             # test.py:42-47
 
 

@@ -131,3 +131,29 @@ def test_f16s_surface(packed_big, lego_rays):
     big["model_fine.linear_feat.weight"][3, 5] = 7.0e4                                      # beyond the f16 range: refused, not clipped
     with pytest.raises(MiNerfError):
         weights.PackedNeRF.from_state_dict(big, DEV).f16s()
+
+
+def test_eval_harness_in_split_precision(tmp_path):
+    """opts.precision = "f16s" takes the eval / video harness (test.py:17-108, 111-174) through the split-precision kernels: the frames
+    are the fp32 harness's within one grey level, PSNR within 0.05 dB (the north star's dataset-level bar)."""
+    from nerf_pytorch_paeng_amd import harness
+    from nerf_pytorch_paeng_amd.model import NeRF, get_positional_encoder
+    D, Wd, Hs, Ws = 4, 256, 20, 24
+    sd = synthetic.make_state_dict(13, D, Wd)
+    model = NeRF(D, Wd, 63, 27).to(DEV)
+    model.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+    posenc = get_positional_encoder(10), get_positional_encoder(4)
+    K = np.array([[30.0, 0, Ws / 2], [0, 30.0, Hs / 2], [0, 0, 1]])
+    poses = harness.get_render_pose(n_angle=3, phi=-30.0, nf=4.0)
+    gt = torch.rand(3, Hs, Ws, 3, generator=torch.Generator().manual_seed(4)).to(DEV)
+    res = {}
+    for mode in ("fp32", "f16s"):
+        opts = make_opts(N_samples_c=32, N_samples_f=32, perturb=0.0, exp_name="x", n_angle=3, single_angle=-1, phi=-30.0, nf=4.0, precision=mode)
+        NP.manual_seed(7)
+        res[mode] = harness.test(0, [0, 1, 2], posenc, model, gt, K, poses.to(DEV), (Hs, Ws), opts, keep_frames=True)
+    for i in range(3):
+        assert abs(res["f16s"]["psnr"][i] - res["fp32"]["psnr"][i]) < 0.05
+        diff = np.abs(res["f16s"]["frames"][i][0].astype(np.int32) - res["fp32"]["frames"][i][0].astype(np.int32))
+        assert diff.max() <= 1 and (diff > 0).mean() < 0.02
+    with pytest.raises(ValueError):
+        harness.test(0, [0], posenc, model, gt, K, poses.to(DEV), (Hs, Ws), make_opts(N_samples_c=32, N_samples_f=32, precision="fp8"))
