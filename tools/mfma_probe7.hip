@@ -21,7 +21,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int QUAD = 1024, SLOTQ = 32, SLOT = SLOTQ * QUAD, NSLOT = 3, NQ = 1184, RD = 3;
-enum { VADDR = 0, SADDR = 1, OFFEN = 2, ADDTID = 3, NONE = 4 };
+enum { VADDR = 0, SADDR = 1, OFFEN = 2, ADDTID = 3, NONE = 4, DWORD = 5, DWORDI = 6 };     // DWORD: four global_load_lds_dword per KiB at one position; DWORDI: one behind each of the quad's four MFMAs
 // STAG: the four waves issue at different quad positions (wave w at 1 + 4 j + w) instead of all four at positions 1..8: the CU's one
 // L1 -> LDS path takes a 1 KiB DMA in 16 cycles, and a wave that finds it busy waits at issue
 
@@ -55,8 +55,30 @@ __device__ __forceinline__ void dma16(const Ring& r, unsigned half) {          /
         asm volatile("buffer_load_dwordx4 off, %0, %1 offset:%2 lds" ::"s"(r.desc), "s"(so), "i"(IMM) : "memory");
     }
 }
+// one 256-byte piece (j = 0..3) of DMA i: a straight copy, LDS byte = stream byte
+template <int IMM>
+__device__ __forceinline__ void dma4(const Ring& r, unsigned half) {
+    const char* g = r.sbase + r.fetch_off + (r.voff >> 2) + half;
+    asm volatile("global_load_lds_dword %0, off offset:%1" ::"v"(g), "i"(IMM) : "memory");
+}
+__device__ __forceinline__ void ring_dma_piece(const Ring& r, int i, int j) {
+    const unsigned half = i >= 4 ? 4096u : 0u;
+    if (i == 0 && j == 0) set_m0(r.fetch_lds);
+    if (i == 4 && j == 0) set_m0(r.fetch_lds + 4096);
+    const int imm = (i & 3) * 1024 + j * 256;
+    switch (imm) {
+#define C(k) case k * 256: dma4<k * 256>(r, half); break;
+        C(0) C(1) C(2) C(3) C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11) C(12) C(13) C(14) C(15)
+#undef C
+    }
+}
 template <int DV>
-__device__ __forceinline__ void ring_dma(const Ring& r, int i) {               // DMA i (0..7) of this wave's 8 KiB share of the slot being fetched
+__device__ __forceinline__ void ring_dma(const Ring& r, int i) {
+    if constexpr (DV == DWORD || DV == DWORDI) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ring_dma_piece(r, i, j);
+        return;
+    }               // DMA i (0..7) of this wave's 8 KiB share of the slot being fetched
     if constexpr (DV == NONE) return;
     const unsigned half = i >= 4 ? 4096u : 0u;
     if (i == 0) set_m0(r.fetch_lds);
@@ -69,7 +91,8 @@ __device__ __forceinline__ void ring_next(Ring& r) {
 }
 template <int DV, int SKEW = 0>
 __device__ __forceinline__ void ring_advance(Ring& r, int wave = 0) {
-    if constexpr (DV != NONE) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if constexpr (DV == DWORD || DV == DWORDI) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+    else if constexpr (DV != NONE) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if constexpr (SKEW > 0)                                                    // wave w leaves the barrier w * SKEW * 16 cycles late: the waves' DMAs no longer meet at the L1 -> LDS path
         for (int i = 0; i < wave * SKEW; ++i) asm volatile("s_nop 15" ::: "memory");
@@ -117,12 +140,15 @@ void probe(const char* __restrict__ stream, const u32x4* __restrict__ bin, float
     for (int s = 0; s < n_slots; ++s) {
         sfor<0, SLOTQ>([&](auto qc) __attribute__((always_inline)) {
             constexpr int q = decltype(qc)::value;
-#pragma unroll
-            for (int p = 0; p < 4; ++p)
-                c[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[q]), __builtin_bit_cast(bf16x8, b[(q & 7) * 4 + p]), c[p], 0, 0, 0);
             constexpr int qr = (q + RD) % SLOTQ;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                c[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[q]), __builtin_bit_cast(bf16x8, b[(q & 7) * 4 + p]), c[p], 0, 0, 0);
+                if constexpr (DV == DWORDI && qr >= 2 && qr <= 9) { ring_dma_piece(r, qr - 2, p); __builtin_amdgcn_sched_barrier(0); }   // one position later: behind the advance
+            }
             if constexpr (q + RD == SLOTQ) ring_advance<DV, SKEW>(r, wave);
-            if constexpr (!STAG) {
+            if constexpr (DV == DWORDI) {
+            } else if constexpr (!STAG) {
                 if constexpr (qr >= 1 && qr <= 8) ring_dma<DV>(r, qr - 1);
             } else if constexpr (qr >= 1) {
                 constexpr int k = qr - 1;                                       // 0..30: wave k % 4 issues its DMA k / 4; the 32nd (wave 3, DMA 7) shares position 31
@@ -179,17 +205,18 @@ int main(int argc, char** argv) {
     hipMemcpy(ds, hs.data(), hs.size() * 4, hipMemcpyHostToDevice); hipMemcpy(db, hb.data(), nb * 16, hipMemcpyHostToDevice);
     const int lds = NSLOT * SLOT;
 #define OPT(k) hipFuncSetAttribute((const void*)(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds)
-    OPT((probe<VADDR>)); OPT((probe<SADDR>)); OPT((probe<OFFEN>)); OPT((probe<ADDTID>)); OPT((probe<NONE>)); OPT((probe<VADDR, true>)); OPT((probe<ADDTID, true>)); OPT((probe<VADDR, false, 1>)); OPT((probe<VADDR, false, 2>)); OPT((probe<ADDTID, false, 1>)); OPT((probe<NONE, false, 1>));
+    OPT((probe<VADDR>)); OPT((probe<SADDR>)); OPT((probe<OFFEN>)); OPT((probe<ADDTID>)); OPT((probe<NONE>)); OPT((probe<DWORD>)); OPT((probe<DWORDI>)); OPT((probe<VADDR, true>)); OPT((probe<ADDTID, true>)); OPT((probe<VADDR, false, 1>)); OPT((probe<VADDR, false, 2>)); OPT((probe<ADDTID, false, 1>)); OPT((probe<NONE, false, 1>));
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int passes = 12;
     const double flop = (double)grid * 4 * passes * NQ * 4 * (2.0 * 16 * 16 * 32);
-    const char* names[] = {"vaddr", "saddr", "offen", "addtid", "none", "vaddr staggered", "addtid staggered", "vaddr skew 16", "vaddr skew 32", "addtid skew 16", "none skew 16"};
+    const char* names[] = {"vaddr", "saddr", "offen", "addtid", "none", "vaddr staggered", "addtid staggered", "vaddr skew 16", "vaddr skew 32", "addtid skew 16", "none skew 16", "4 x dword burst", "4 x dword behind MFMAs"};
     std::vector<float> ref(on), got(on);
     {
         u32x4* dchk; hipMalloc(&dchk, SLOT);
         std::vector<unsigned> hc(SLOT / 4);
-        for (int v = 0; v < 4; ++v) {
+        for (int v = 0; v < 5; ++v) {
             switch (v) {
+                case 4: OPT((fill_check<DWORD>)); hipLaunchKernelGGL((fill_check<DWORD>), dim3(1), dim3(256), lds, 0, ds, dchk); break;
                 case 0: OPT((fill_check<VADDR>)); hipLaunchKernelGGL((fill_check<VADDR>), dim3(1), dim3(256), lds, 0, ds, dchk); break;
                 case 1: OPT((fill_check<SADDR>)); hipLaunchKernelGGL((fill_check<SADDR>), dim3(1), dim3(256), lds, 0, ds, dchk); break;
                 case 2: OPT((fill_check<OFFEN>)); hipLaunchKernelGGL((fill_check<OFFEN>), dim3(1), dim3(256), lds, 0, ds, dchk); break;
@@ -199,7 +226,7 @@ int main(int argc, char** argv) {
             hipMemcpy(hc.data(), dchk, SLOT, hipMemcpyDeviceToHost);
             size_t bad = 0, first = (size_t)-1;
             for (size_t i = 0; i < SLOT / 4; ++i) if (hc[i] != hs[SLOT / 4 + i]) { if (!bad) first = i; ++bad; }
-            printf("%-7s slot image: %zu of %d dwords wrong", names[v], bad, SLOT / 4);
+            printf("%-7s slot image: %zu of %d dwords wrong", v == 4 ? "4xdword" : names[v], bad, SLOT / 4);
             if (bad) printf(" (first at dword %zu: got %08x want %08x)", first, hc[first], hs[SLOT / 4 + first]);
             printf("\n");
         }
@@ -223,7 +250,7 @@ int main(int argc, char** argv) {
         }
     }
     for (int round = 0; round < 5; ++round)
-        for (int v = 0; v < 11; ++v) {
+        for (int v = 0; v < 13; ++v) {
             float ms = 0;
             for (int rep = 0; rep < 6; ++rep) {
                 hipEventRecord(e0);
@@ -239,6 +266,8 @@ int main(int argc, char** argv) {
                     case 8: hipLaunchKernelGGL((probe<VADDR, false, 2>), dim3(grid), dim3(256), lds, 0, ds, db, dout, passes); break;
                     case 9: hipLaunchKernelGGL((probe<ADDTID, false, 1>), dim3(grid), dim3(256), lds, 0, ds, db, dout, passes); break;
                     case 10: hipLaunchKernelGGL((probe<NONE, false, 1>), dim3(grid), dim3(256), lds, 0, ds, db, dout, passes); break;
+                    case 11: hipLaunchKernelGGL((probe<DWORD>), dim3(grid), dim3(256), lds, 0, ds, db, dout, passes); break;
+                    case 12: hipLaunchKernelGGL((probe<DWORDI>), dim3(grid), dim3(256), lds, 0, ds, db, dout, passes); break;
                 }
                 hipEventRecord(e1); hipEventSynchronize(e1);
                 float t; hipEventElapsedTime(&t, e0, e1); if (rep >= 2) ms += t / 4;
