@@ -149,6 +149,17 @@ size_t mi_nerf_packed_bytes_f16s(const mi_nerf_net* net);
 int mi_nerf_pack_weights_f16s(const mi_nerf_net* net, const mi_nerf_params* params, void* host_blob, size_t blob_bytes);
 int mi_nerf_mlp_rays_f16s(const mi_nerf_net* net, const void* packed_f16s_dev, const float* rays_dev, const float* z_dev,
                           int64_t n_rays, int S, float* raw_dev, void* stream);
+/* ... as the TRAINING forward (replaces mi_nerf_mlp_rays_train, i.e. model/NeRF.py:33-52 with the graph autograd would record): the same
+ * outputs plus the same activation stash in the same layouts, so mi_nerf_mlp_backward runs unchanged behind it.  The weights change
+ * every step: mi_nerf_pack_apply_f16s re-packs on the device from the flat parameter vector (module.parameters() order) through a
+ * gather map built once (mi_nerf_pack_map_f16s; mi_nerf_pack_map_f16s_len entries).  out_of_range_dev (may be NULL): incremented once
+ * per stream element whose weight is NaN or beyond the f16 range -- what the host packer refuses. */
+int mi_nerf_mlp_rays_train_f16s(const mi_nerf_net* net, const void* packed_f16s_dev, const float* rays_dev, const float* z_dev,
+                                int64_t n_rays, int S, float* raw_dev, void* stash_dev, size_t stash_bytes, void* stream);
+size_t mi_nerf_pack_map_f16s_len(const mi_nerf_net* net);
+int mi_nerf_pack_map_f16s(const mi_nerf_net* net, int32_t* map_host, size_t map_len);
+int mi_nerf_pack_apply_f16s(const mi_nerf_net* net, const int32_t* map_dev, const float* flat_dev, void* blob_dev, size_t blob_bytes,
+                            uint32_t* out_of_range_dev, void* stream);
 
 /* a10 post_process(outputs, z_vals, rays_d)                              nerf_process.py:89-140
  * raw [n,S,4], z [n,S], rays [n, ray_stride] with the direction at floats 3..5 when ray_stride == 6, or a

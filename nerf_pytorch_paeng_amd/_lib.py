@@ -91,6 +91,10 @@ SIGNATURES = {
     "mi_nerf_pack_apply_bf16": (_I, [_NETP, _P, _P, _P, _SZ, _P]),
     "mi_nerf_train_layout_query": (_I, [_NETP, _I64, _I, C.POINTER(TrainLayout)]),
     "mi_nerf_mlp_rays_train": (_I, [_NETP, _P, _P, _P, _I64, _I, _P, _P, _SZ, _P]),
+    "mi_nerf_mlp_rays_train_f16s": (_I, [_NETP, _P, _P, _P, _I64, _I, _P, _P, _SZ, _P]),
+    "mi_nerf_pack_map_f16s_len": (_SZ, [_NETP]),
+    "mi_nerf_pack_map_f16s": (_I, [_NETP, _P, _SZ]),
+    "mi_nerf_pack_apply_f16s": (_I, [_NETP, _P, _P, _P, _SZ, _P, _P]),
     "mi_nerf_mlp_backward": (_I, [_NETP, _P, _P, _P, _P, _I64, _I, _P, _P, _P, _SZ, _P, _I, _P]),
     "mi_nerf_mlp_embedded_train": (_I, [_NETP, _P, _P, _I64, _P, _P, _SZ, _P]),
     "mi_nerf_mlp_embedded_backward": (_I, [_NETP, _P, _P, _P, _I64, _P, _P, _P, _SZ, _P, _P]),

@@ -55,6 +55,11 @@ int mlp_rays_bf16(const mi_nerf_net*, const void*, const float*, const float*, i
 size_t packed_bytes_f16s(const mi_nerf_net*);
 int pack_f16s(const mi_nerf_net*, const mi_nerf_params*, void*, size_t);
 int mlp_rays_f16s(const mi_nerf_net*, const void*, const float*, const float*, int64_t, int, float*, hipStream_t);
+int mlp_rays_f16s_stash(const mi_nerf_net*, const void*, const float*, const float*, int64_t, int, float*, float*, float*, float*, unsigned*, unsigned*,
+                        hipStream_t);
+size_t pack_map_f16s_len(const mi_nerf_net*);
+int pack_map_f16s(const mi_nerf_net*, int32_t*, size_t);
+int pack_apply_f16s(const mi_nerf_net*, const int32_t*, const float*, void*, size_t, unsigned*, hipStream_t);
 // the MLP launch of a given precision mode (mi_nerf_render_cfg.use_bf16 / mi_nerf_time_mlp_rays): 0 fp32 MFMA; 1..4 bf16 (launch shape);
 // 5 f16 split precision (fp32-grade results on the f16 matrix pipe, mlp_f16s.hip)
 #define MI_NERF_MODE_F16S 5
@@ -292,6 +297,31 @@ int mi_nerf_mlp_rays_train(const mi_nerf_net* net, const void* packed, const flo
     return mlp_rays_fp32_stash(net, packed, rays, z, n_rays, S, raw, (float*)((char*)stash + L.stash_h), (float*)((char*)stash + L.stash_f),
                                (float*)((char*)stash + L.stash_g), (unsigned*)((char*)stash + L.mask_h), (unsigned*)((char*)stash + L.mask_g),
                                (hipStream_t)st);
+}
+int mi_nerf_mlp_rays_train_f16s(const mi_nerf_net* net, const void* packed_f16s, const float* rays, const float* z, int64_t n_rays, int S,
+                                float* raw, void* stash, size_t stash_bytes, void* st) {
+    if (int rc = check_net_basic(net)) return rc;
+    MN_CHECK_ARG(n_rays >= 0 && S >= 1, "bad sizes n_rays=%lld S=%d", (long long)n_rays, S);
+    mi_nerf_train_layout L;
+    if (int rc = train_layout(net, n_rays, S, &L)) return rc;
+    if (n_rays == 0) return MI_NERF_OK;
+    MN_CHECK_ARG(stash != nullptr && stash_bytes >= L.stash_bytes, "stash too small: %zu < %zu", stash_bytes, L.stash_bytes);
+    return mlp_rays_f16s_stash(net, packed_f16s, rays, z, n_rays, S, raw, (float*)((char*)stash + L.stash_h), (float*)((char*)stash + L.stash_f),
+                               (float*)((char*)stash + L.stash_g), (unsigned*)((char*)stash + L.mask_h), (unsigned*)((char*)stash + L.mask_g),
+                               (hipStream_t)st);
+}
+size_t mi_nerf_pack_map_f16s_len(const mi_nerf_net* net) {
+    if (!net) return 0;
+    return pack_map_f16s_len(net);
+}
+int mi_nerf_pack_map_f16s(const mi_nerf_net* net, int32_t* map_host, size_t map_len) {
+    MN_CHECK_ARG(net && map_host, "NULL pointer");
+    return pack_map_f16s(net, map_host, map_len);
+}
+int mi_nerf_pack_apply_f16s(const mi_nerf_net* net, const int32_t* map_dev, const float* flat_dev, void* blob_dev, size_t blob_bytes,
+                            uint32_t* out_of_range_dev, void* st) {
+    MN_CHECK_ARG(net, "net is NULL");
+    return pack_apply_f16s(net, map_dev, flat_dev, blob_dev, blob_bytes, out_of_range_dev, (hipStream_t)st);
 }
 int mi_nerf_mlp_backward(const mi_nerf_net* net, const void* packed, const void* packed_bwd, const float* rays, const float* z,
                          int64_t n_rays, int S, const float* d_raw, const void* stash, void* work, size_t work_bytes, float* grads,

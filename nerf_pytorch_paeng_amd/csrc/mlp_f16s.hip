@@ -107,17 +107,18 @@ static inline void split_weight(float w, uint16_t& hi, uint16_t& lo) {
 
 // One quad PAIR: the (hi, lo) A fragments of output rows row0..row0+15 for the 32 input columns cols[q*8 + j] (-1: zero).
 // rowmap (optional, 16 entries): weight-matrix row feeding output row i of the tile, -1: zero row.
-static void emit_pair(std::vector<uint16_t>& st, const float* Wm, int n_out, int n_in, int row0, const int* rowmap, const int* cols) {
+// The stream is built as VALUES first (the source weight at its hi AND its lo position: element i of a 1024-element pair block is a hi
+// half for i < 512, a lo half otherwise), so that the same routine over index-valued weights yields the device packer's gather map.
+static void emit_pair(std::vector<float>& st, const float* Wm, int n_out, int n_in, int row0, const int* rowmap, const int* cols) {
     const size_t base = st.size();
-    st.resize(base + 2 * 512);
+    st.resize(base + 2 * 512, 0.0f);
     for (int lane = 0; lane < 64; ++lane)
         for (int j = 0; j < 8; ++j) {
             const int col = cols[(lane >> 4) * 8 + j];
             const int n = rowmap ? rowmap[lane & 15] : row0 + (lane & 15);
-            uint16_t hi = 0, lo = 0;
-            if (col >= 0 && n >= 0 && n < n_out) split_weight(Wm[(size_t)n * n_in + col], hi, lo);
-            st[base + lane * 8 + j] = hi;
-            st[base + 512 + lane * 8 + j] = lo;
+            const float w = (col >= 0 && n >= 0 && n < n_out) ? Wm[(size_t)n * n_in + col] : 0.0f;
+            st[base + lane * 8 + j] = w;
+            st[base + 512 + lane * 8 + j] = w;
         }
 }
 static std::vector<int> enc_cols(int L, int base) {           // L: the network's own frequencies; the k-step count is the kernel's
@@ -134,7 +135,7 @@ static std::vector<int> act_cols(int W, int base) {
             for (int j = 0; j < 8; ++j) c.push_back(base + MT * (2 * s + (j >> 2)) + 4 * q + (j & 3));
     return c;
 }
-static void emit_layer(std::vector<uint16_t>& st, const float* Wm, int n_out, int n_in, int nt, const std::vector<int>& cols) {
+static void emit_layer(std::vector<float>& st, const float* Wm, int n_out, int n_in, int nt, const std::vector<int>& cols) {
     const int KS = (int)cols.size() / KF;
     for (int tile = 0; tile < nt; ++tile)
         for (int ks = 0; ks < KS; ++ks) emit_pair(st, Wm, n_out, n_in, MT * tile, nullptr, cols.data() + KF * ks);
@@ -159,23 +160,12 @@ size_t packed_bytes_f16s(const mi_nerf_net* net) {
     return f16s::make_layout(net->D, net->W, net->skip).total_bytes;
 }
 
-int pack_f16s(const mi_nerf_net* net, const mi_nerf_params* p, void* blob, size_t blob_bytes) {
-    using namespace f16s;
-    if (int rc = check_net(net)) return rc;
+namespace f16s {
+// value stream of a network (see emit_pair) and its side tables
+static int build_stream(const mi_nerf_net* net, const mi_nerf_params* p, const BlobLayoutS& L, std::vector<float>& st) {
     const int D = net->D, W = net->W;
     const int in_x = 3 + 6 * net->L_x, in_d = 3 + 6 * net->L_d;
-    const BlobLayoutS L = make_layout(D, W, net->skip);
-    MN_CHECK_ARG(blob_bytes >= L.total_bytes, "blob too small: %zu < %u", blob_bytes, L.total_bytes);
-    for (int l = 0; l < D; ++l) {
-        const int n_in = l == 0 ? in_x : ((net->skip >= 0 && l == net->skip + 1) ? W + in_x : W);
-        if (int rc = check_weights(p->linear_x_w[l], (size_t)W * n_in, "linear_x.weight")) return rc;
-    }
-    if (int rc = check_weights(p->linear_feat_w, (size_t)W * W, "linear_feat.weight")) return rc;
-    if (int rc = check_weights(p->linear_density_w, W, "linear_density.weight")) return rc;
-    if (int rc = check_weights(p->linear_d_w, (size_t)(W / 2) * (W + in_d), "linear_d.weight")) return rc;
-    if (int rc = check_weights(p->linear_color_w, (size_t)3 * (W / 2), "linear_color.weight")) return rc;
-    memset(blob, 0, L.total_bytes);
-    std::vector<uint16_t> st;
+    st.clear();
     st.reserve(L.stream_bytes / 2);
     emit_layer(st, p->linear_x_w[0], W, in_x, NT, enc_cols(net->L_x, 0));
     for (int l = 1; l < D; ++l) {
@@ -201,14 +191,12 @@ int pack_f16s(const mi_nerf_net* net, const mi_nerf_params* p, void* blob, size_
         for (int i = 0; i < MT; ++i) rowmap[i] = (i < 3) ? i : -1;      // output rows 0..2 <- linear_color rows 0..2
         for (int ks = 0; ks < W / 2 / KF; ++ks) emit_pair(st, p->linear_color_w, 3, W / 2, 0, rowmap, act.data() + KF * ks);
     }
-    st.resize(st.size() + (size_t)(TAIL_PAIRS - TAIL_USED_P) * 2 * 512, (uint16_t)0);
+    st.resize(st.size() + (size_t)(TAIL_PAIRS - TAIL_USED_P) * 2 * 512, 0.0f);
     MN_CHECK_ARG(st.size() * 2 == L.stream_bytes, "internal: f16-split stream %zu != %u", st.size() * 2, L.stream_bytes);
-    uint32_t* hdr = (uint32_t*)blob;
-    hdr[0] = BLOB_MAGIC; hdr[1] = 4; hdr[2] = D; hdr[3] = W; hdr[4] = (uint32_t)net->skip; hdr[5] = KERNEL_LX; hdr[6] = KERNEL_LD;
-    hdr[7] = L.stream_off; hdr[8] = L.stream_bytes; hdr[9] = L.stream_bytes; hdr[10] = L.side_off; hdr[11] = L.side_floats;
-    hdr[12] = 2; hdr[13] = net->L_x; hdr[14] = net->L_d;
-    memcpy((char*)blob + L.stream_off, st.data(), L.stream_bytes);
-    float* side = (float*)((char*)blob + L.side_off);
+    return MI_NERF_OK;
+}
+static void fill_side(const mi_nerf_net* net, const mi_nerf_params* p, const BlobLayoutS& L, float* side) {
+    const int D = net->D, W = net->W, in_d = 3 + 6 * net->L_d;
     for (int l = 0; l < D; ++l) memcpy(side + L.bias_trunk + (size_t)l * W, p->linear_x_b[l], W * 4);
     memcpy(side + L.bias_feat, p->linear_feat_b, W * 4);
     memcpy(side + L.bias_d, p->linear_d_b, (W / 2) * 4);
@@ -216,6 +204,112 @@ int pack_f16s(const mi_nerf_net* net, const mi_nerf_params* p, void* blob, size_
     side[L.head_b + 3] = p->linear_density_b[0];
     for (int f = 0; f < in_d; ++f)
         for (int n = 0; n < W / 2; ++n) side[L.wdir_t + (size_t)f * (W / 2) + n] = p->linear_d_w[(size_t)n * (W + in_d) + W + f];
+}
+static void fill_header(const mi_nerf_net* net, const BlobLayoutS& L, uint32_t* hdr) {
+    memset(hdr, 0, HEADER_BYTES);
+    hdr[0] = BLOB_MAGIC; hdr[1] = 4; hdr[2] = net->D; hdr[3] = net->W; hdr[4] = (uint32_t)net->skip; hdr[5] = KERNEL_LX; hdr[6] = KERNEL_LD;
+    hdr[7] = L.stream_off; hdr[8] = L.stream_bytes; hdr[9] = L.stream_bytes; hdr[10] = L.side_off; hdr[11] = L.side_floats;
+    hdr[12] = 2; hdr[13] = net->L_x; hdr[14] = net->L_d;
+}
+}  // namespace f16s
+
+int pack_f16s(const mi_nerf_net* net, const mi_nerf_params* p, void* blob, size_t blob_bytes) {
+    using namespace f16s;
+    if (int rc = check_net(net)) return rc;
+    const int D = net->D, W = net->W;
+    const int in_x = 3 + 6 * net->L_x, in_d = 3 + 6 * net->L_d;
+    const BlobLayoutS L = make_layout(D, W, net->skip);
+    MN_CHECK_ARG(blob_bytes >= L.total_bytes, "blob too small: %zu < %u", blob_bytes, L.total_bytes);
+    for (int l = 0; l < D; ++l) {
+        const int n_in = l == 0 ? in_x : ((net->skip >= 0 && l == net->skip + 1) ? W + in_x : W);
+        if (int rc = check_weights(p->linear_x_w[l], (size_t)W * n_in, "linear_x.weight")) return rc;
+    }
+    if (int rc = check_weights(p->linear_feat_w, (size_t)W * W, "linear_feat.weight")) return rc;
+    if (int rc = check_weights(p->linear_density_w, W, "linear_density.weight")) return rc;
+    if (int rc = check_weights(p->linear_d_w, (size_t)(W / 2) * (W + in_d), "linear_d.weight")) return rc;
+    if (int rc = check_weights(p->linear_color_w, (size_t)3 * (W / 2), "linear_color.weight")) return rc;
+    memset(blob, 0, L.total_bytes);
+    std::vector<float> st;
+    if (int rc = build_stream(net, p, L, st)) return rc;
+    fill_header(net, L, (uint32_t*)blob);
+    uint16_t* out = (uint16_t*)((char*)blob + L.stream_off);
+    for (size_t i = 0; i < st.size(); ++i) {
+        uint16_t hi, lo;
+        split_weight(st[i], hi, lo);
+        out[i] = (i & 1023) < 512 ? hi : lo;
+    }
+    fill_side(net, p, L, (float*)((char*)blob + L.side_off));
+    return MI_NERF_OK;
+}
+
+// Device-side re-pack (the training path packs after every optimizer step): gather map over the FLAT parameter vector
+// (module.parameters() order, layout.h make_param_offsets), built by running the routines above over index-valued weights.
+// map[i], i < stream elements: 1 + flat index feeding stream element i (0: zero); then the side table's floats.
+size_t pack_map_f16s_len(const mi_nerf_net* net) {
+    if (f16s::check_net(net)) return 0;
+    const f16s::BlobLayoutS L = f16s::make_layout(net->D, net->W, net->skip);
+    return (size_t)L.stream_bytes / 2 + L.side_floats;
+}
+int pack_map_f16s(const mi_nerf_net* net, int32_t* map, size_t map_len) {
+    using namespace f16s;
+    if (int rc = check_net(net)) return rc;
+    const int D = net->D, W = net->W;
+    const BlobLayoutS L = make_layout(D, W, net->skip);
+    const ParamOffsets po = make_param_offsets(D, W, net->skip, net->L_x, net->L_d);
+    MN_CHECK_ARG(po.total < (1u << 24), "network too large for the index map (%u parameters)", po.total);
+    const size_t n_stream = (size_t)L.stream_bytes / 2;
+    MN_CHECK_ARG(map && map_len >= n_stream + L.side_floats, "map too small: %zu entries for %zu", map_len, n_stream + L.side_floats);
+    std::vector<float> flat(po.total);
+    for (uint32_t i = 0; i < po.total; ++i) flat[i] = (float)(i + 1);
+    std::vector<const float*> wx(D), bx(D);
+    for (int l = 0; l < D; ++l) { wx[l] = flat.data() + po.w_x[l]; bx[l] = flat.data() + po.b_x[l]; }
+    mi_nerf_params p{};
+    p.linear_x_w = wx.data(); p.linear_x_b = bx.data();
+    p.linear_density_w = flat.data() + po.w_dens; p.linear_density_b = flat.data() + po.b_dens;
+    p.linear_feat_w = flat.data() + po.w_feat; p.linear_feat_b = flat.data() + po.b_feat;
+    p.linear_d_w = flat.data() + po.w_d; p.linear_d_b = flat.data() + po.b_d;
+    p.linear_color_w = flat.data() + po.w_color; p.linear_color_b = flat.data() + po.b_color;
+    std::vector<float> st;
+    if (int rc = build_stream(net, &p, L, st)) return rc;
+    std::vector<float> side(L.side_floats, 0.0f);
+    fill_side(net, &p, L, side.data());
+    for (size_t i = 0; i < n_stream; ++i) map[i] = (int32_t)st[i];
+    for (size_t i = 0; i < L.side_floats; ++i) map[n_stream + i] = (int32_t)side[i];
+    return MI_NERF_OK;
+}
+
+namespace f16s {
+struct HeaderWordsS { uint32_t w[HEADER_BYTES / 4]; };
+__global__ __launch_bounds__(256) void pack_apply_f16s_kernel(const int32_t* __restrict__ map, const float* __restrict__ flat, unsigned n_stream,
+                                                               unsigned n_side, unsigned stream_off, unsigned side_off, HeaderWordsS hdr,
+                                                               char* __restrict__ blob, unsigned* __restrict__ bad) {
+    const unsigned i = blockIdx.x * 256 + threadIdx.x;
+    if (i < HEADER_BYTES / 4) ((uint32_t*)blob)[i] = hdr.w[i];
+    if (i < n_stream) {
+        const int32_t m = map[i];
+        const float w = m ? flat[m - 1] : 0.0f;
+        if (!(__builtin_fabsf(w) < 65504.0f) && bad) atomicAdd(bad, 1u);          // NaN or beyond the f16 range: the host packer refuses these
+        const _Float16 hi = (_Float16)w;                                          // round to nearest even, like f32_to_f16_rne
+        const _Float16 lo = (_Float16)((w - (float)hi) * SC_UP);
+        ((_Float16*)(blob + stream_off))[i] = (i & 1023u) < 512u ? hi : lo;
+    } else if (i < n_stream + n_side) {
+        const int32_t m = map[i];
+        ((float*)(blob + side_off))[i - n_stream] = m ? flat[m - 1] : 0.0f;
+    }
+}
+}  // namespace f16s
+int pack_apply_f16s(const mi_nerf_net* net, const int32_t* map_dev, const float* flat_dev, void* blob_dev, size_t blob_bytes, unsigned* bad_dev, hipStream_t st) {
+    using namespace f16s;
+    if (int rc = check_net(net)) return rc;
+    const BlobLayoutS L = make_layout(net->D, net->W, net->skip);
+    MN_CHECK_ARG(map_dev && flat_dev && blob_dev, "NULL device pointer");
+    MN_CHECK_ARG(blob_bytes >= L.total_bytes && ((uintptr_t)blob_dev & 15) == 0, "blob too small (%zu < %u) or not 16-byte aligned", blob_bytes, L.total_bytes);
+    HeaderWordsS h;
+    fill_header(net, L, h.w);
+    const unsigned n_stream = L.stream_bytes / 2, total = n_stream + L.side_floats;
+    hipLaunchKernelGGL(pack_apply_f16s_kernel, dim3((total + 255) / 256), dim3(256), 0, st, map_dev, flat_dev, n_stream, L.side_floats, L.stream_off,
+                       L.side_off, h, (char*)blob_dev, bad_dev);
+    MN_LAUNCH_CHECK("pack_apply_f16s_kernel");
     return MI_NERF_OK;
 }
 
@@ -236,6 +330,13 @@ struct Args {
     int S, tpr, D, skip_layer;
     unsigned stream_bytes, side_floats;
     unsigned o_bias_trunk, o_bias_feat, o_bias_d, o_head_b, o_wdir_t;
+    // STASH instantiation (training forward): what mlp_fp32_kernel<..., STASH = true> leaves for the backward pass, in ITS layouts
+    float* stash_h;             // [D][P][W]   post-ReLU output of trunk layer l
+    float* stash_f;             // [P][W]      linear_feat output
+    float* stash_g;             // [P][W/2]    post-ReLU linear_d output
+    unsigned* mask_h;           // [D][n_wtiles][64][4]  ReLU' bits of stash_h in the fp32 kernel's lane / register order (mlp_core.h mask_pack_chunk)
+    unsigned* mask_g;           // [n_wtiles][64][2]     ... of stash_g
+    long long stash_rows;       // P
 };
 
 struct Ring {
@@ -336,8 +437,7 @@ __device__ __forceinline__ void pack_stage(const float h0, const float h1, const
     } else asm volatile("v_accvgpr_write_b32 a[%2], %0\n\tv_accvgpr_write_b32 a[%3], %1" ::"v"(t.hi), "v"(t.lo), "n"(RH), "n"(RL));
 }
 template <bool RELU, int RH, int RL>
-__device__ __forceinline__ void pack_block(const float h0, const float h1, const float l0, const float l1, float dn, float up, float nup) {
-    PairTmp t;
+__device__ __forceinline__ void pack_block(const float h0, const float h1, const float l0, const float l1, PairTmp& t, float dn, float up, float nup) {
     pack_stage<RELU, RH, RL, 0>(h0, h1, l0, l1, t, dn, up, nup); pack_stage<RELU, RH, RL, 1>(h0, h1, l0, l1, t, dn, up, nup);
     pack_stage<RELU, RH, RL, 2>(h0, h1, l0, l1, t, dn, up, nup); pack_stage<RELU, RH, RL, 3>(h0, h1, l0, l1, t, dn, up, nup);
     pack_stage<RELU, RH, RL, 4>(h0, h1, l0, l1, t, dn, up, nup); pack_stage<RELU, RH, RL, 5>(h0, h1, l0, l1, t, dn, up, nup);
@@ -355,9 +455,49 @@ __device__ __forceinline__ void pack_sched(const f32x4 (&ph)[NP], const f32x4 (&
 }
 // ... and the block form for short jobs: pair n (0..3) whole, in one gap
 template <bool RELU, int SET, int T, int PAIR>
-__device__ __forceinline__ void pack_pair_block(const f32x4 (&ph)[NP], const f32x4 (&pl)[NP], float dn, float up, float nup) {
+__device__ __forceinline__ void pack_pair_block(const f32x4 (&ph)[NP], const f32x4 (&pl)[NP], PairTmp (&t)[4], float dn, float up, float nup) {
     constexpr int p = PAIR >> 1, e = PAIR & 1;
-    pack_block<RELU, tile_reg(SET, p, T, 0) + e, tile_reg(SET, p, T, 1) + e>(ph[p][2 * e], ph[p][2 * e + 1], pl[p][2 * e], pl[p][2 * e + 1], dn, up, nup);
+    pack_block<RELU, tile_reg(SET, p, T, 0) + e, tile_reg(SET, p, T, 1) + e>(ph[p][2 * e], ph[p][2 * e + 1], pl[p][2 * e], pl[p][2 * e + 1], t[PAIR], dn, up, nup);
+}
+
+// ---- STASH (training forward): a packed tile also leaves its four values per lane (features 16 T + 4 q4 + {0..3} of one point) as a
+// 16-byte piece of the point's row, and -- ReLU layers -- their ReLU' bits in the layout mlp_dgrad_kernel reads.  That kernel's lane
+// (j, hh) holds, for point j of the 32-point tile, the features f with (f >> 2) & 1 == hh, bit 31 - (4 ((f >> 3) & 7) + (f & 3)) of word
+// f >> 6 (mlp_core.h mask_pack_chunk).  Here lane (q4, col) of point tile p holds f = 16 T + 4 q4 + i: hh = q4 & 1, word T >> 2, nibble
+// (2 T + (q4 >> 1)) & 7 counted from the top.  Lanes q4 and q4 ^ 2 (lane ^ 32) fill alternate nibbles of the same words: the layer's
+// words are OR-ed across that pair once, at the end (finish_masks).
+template <bool RELU, bool MASK, int T>
+__device__ __forceinline__ void stash_tile(const PairTmp& e0, const PairTmp& e1, float* rowp, unsigned (&mw)[4], unsigned nib_sh) {
+    f32x4 v;
+    if constexpr (RELU) {              // operand order pinned: max(+0, -0) must come out +0 (the bits double as the mask)
+        asm volatile("v_max_f32 %0, 0, %1" : "=v"(v[0]) : "v"(e0.y0));
+        asm volatile("v_max_f32 %0, 0, %1" : "=v"(v[1]) : "v"(e0.y1));
+        asm volatile("v_max_f32 %0, 0, %1" : "=v"(v[2]) : "v"(e1.y0));
+        asm volatile("v_max_f32 %0, 0, %1" : "=v"(v[3]) : "v"(e1.y1));
+    } else { v[0] = e0.y0; v[1] = e0.y1; v[2] = e1.y0; v[3] = e1.y1; }
+    *(f32x4*)(rowp + MT * T) = v;
+    if constexpr (MASK) {
+        unsigned b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("v_min_u32 %0, 1, %1" : "=v"(b[i]) : "v"(v[i]));     // post-ReLU: non-zero bits == positive
+        const unsigned nib = (((b[0] << 1) | b[1]) << 2) | ((b[2] << 1) | b[3]);
+        mw[T >> 2] |= (nib << nib_sh) << (24 - 8 * (T & 3));
+    }
+}
+// the layer's mask words of both point tiles, completed across the lane pair and written in the backward kernel's order; words cleared
+template <int NWORD>
+__device__ __forceinline__ void finish_masks(unsigned (&mw)[NP][4], unsigned* dst_tile, int col, int q4, bool active) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        unsigned w[NWORD];
+#pragma unroll
+        for (int k = 0; k < NWORD; ++k) { w[k] = mw[p][k] | (unsigned)__shfl_xor((int)mw[p][k], 32, 64); mw[p][k] = 0u; }
+        if (active && q4 < 2) {
+            unsigned* d = dst_tile + (size_t)(col + 16 * p + 32 * (q4 & 1)) * NWORD;
+            if constexpr (NWORD == 4) { u32x4b m; m[0] = w[0]; m[1] = w[1]; m[2] = w[2]; m[3] = w[3]; *(u32x4b*)d = m; }
+            else { d[0] = w[0]; d[1] = w[1]; }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -395,6 +535,7 @@ __device__ __forceinline__ void job(f32x4 (&ah)[NP], f32x4 (&al)[NP], CSel csel,
     });
 }
 
+template <bool STASH>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void mlp_f16s_kernel(const Args a) {
     constexpr int W = 256, LX = KERNEL_LX, LD = KERNEL_LD, IN_X = 3 + 6 * LX, IN_D = 3 + 6 * LD;
@@ -455,6 +596,19 @@ void mlp_f16s_kernel(const Args a) {
     f32x4 cin, cnext;                                        // bias of the current / next job (shared by the point tiles)
     auto csel1 = [&](int) __attribute__((always_inline)) -> const f32x4& { return cin; };
     u32x4b peh[NP][KPE], pel[NP][KPE];
+    // STASH: row pointers of the tensor being written (this lane's 16-byte column of its two points), the running layer's ReLU' words
+    float* rowp[NP] = {nullptr, nullptr};
+    unsigned mw[NP][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+    const unsigned nib_sh = (q4 >> 1) ? 0u : 4u;
+    unsigned tile_cur = 0; bool tile_active = false; int lyr = 0;
+    auto end_trunk_layer = [&]() __attribute__((always_inline)) {          // after the job that packed (and stashed) a trunk layer's last tile
+        if constexpr (STASH) {
+            finish_masks<4>(mw, a.mask_h + ((size_t)lyr * a.n_wtiles + tile_cur) * 256, col, q4, tile_active);
+            ++lyr;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) rowp[p] += a.stash_rows * W;
+        }
+    };
 
     // A trunk layer reads fragment set SIN (the second half of fragment 7 is still being packed from the previous tiles when it
     // starts), writes set 1 - SIN, leaves its last tile in ph / pl; the bias of the NEXT job is read while a job's last groups compute.
@@ -480,6 +634,8 @@ void mlp_f16s_kernel(const Args a) {
                 constexpr int ks = decltype(ks_c)::value, sub = decltype(s_c)::value;
                 if constexpr (t == 0) pack_sched<true, SIN, NT - 1, ks, sub>(ph, pl, pt, dn, up, nup);
                 else pack_sched<true, SOUT, t - 1, ks, sub>(ph, pl, pt, dn, up, nup);
+                if constexpr (STASH && ks == 7 && (sub == 3 || sub == 4))      // the tile just packed: its rows and ReLU' bits
+                    stash_tile<true, true, (t == 0 ? NT - 1 : t - 1)>(pt[2 * (sub - 3)], pt[2 * (sub - 3) + 1], rowp[sub - 3], mw[sub - 3], nib_sh);
                 if constexpr (ks == 7 && sub == 2) {              // bias of the next job (C operand of its first MFMAs)
                     const float* v = (t + 1 < NT) ? bias + MT * (t + 1) + 4 * q4 : next_bias + 4 * q4;
                     cnext = *(const f32x4*)v;
@@ -494,6 +650,7 @@ void mlp_f16s_kernel(const Args a) {
 #pragma unroll
             for (int p = 0; p < NP; ++p) { ph[p] = ah[p]; pl[p] = al[p]; }
             cin = cnext;
+            if constexpr (t == 0) end_trunk_layer();             // job 0 packed the PREVIOUS layer's last tile
         });
     };
 
@@ -508,6 +665,11 @@ void mlp_f16s_kernel(const Args a) {
             const int sample = (int)chunk * 32 + 16 * h + col;
             valid[h] = active && sample < a.S;
             out_idx[h] = (size_t)tray * a.S + (sample < a.S ? sample : a.S - 1);
+        }
+        if constexpr (STASH) {
+            tile_cur = tcur; tile_active = active; lyr = 0;
+#pragma unroll
+            for (int h = 0; h < NP; ++h) rowp[h] = a.stash_h + out_idx[h] * W + 4 * q4;
         }
         const float in_o[3] = {nx_r[0], nx_r[1], nx_r[2]}, in_d[3] = {nx_r[3], nx_r[4], nx_r[5]};
         const float in_z = nx_z;
@@ -597,10 +759,13 @@ void mlp_f16s_kernel(const Args a) {
             auto bl = [&](auto p_c, auto ks_c) __attribute__((always_inline)) -> const u32x4b& { return pel[decltype(p_c)::value][decltype(ks_c)::value]; };
             static_for<0, NT>([&](auto t_c) __attribute__((always_inline)) {
                 constexpr int t = decltype(t_c)::value;
+                PairTmp pt[4];
                 auto hook = [&](auto ks_c, auto s_c) __attribute__((always_inline)) {
                     constexpr int ks = decltype(ks_c)::value, sub = decltype(s_c)::value;
                     // 12 MFMAs per job and four pairs to pack: a whole pair per gap (these jobs run VALU bound; 3 % of the MFMAs)
-                    if constexpr (t > 0 && ks == 0 && sub >= 2) pack_pair_block<true, 0, t - 1, sub - 2>(ph, pl, dn, up, nup);
+                    if constexpr (t > 0 && ks == 0 && sub >= 2) pack_pair_block<true, 0, t - 1, sub - 2>(ph, pl, pt, dn, up, nup);
+                    if constexpr (STASH && t > 0 && ks == 1 && (sub == 3 || sub == 4))
+                        stash_tile<true, true, t - 1>(pt[2 * (sub - 3)], pt[2 * (sub - 3) + 1], rowp[sub - 3], mw[sub - 3], nib_sh);
                     if constexpr (ks == 1 && sub == 2) {
                         const float* v = (t + 1 < NT) ? b0 + MT * (t + 1) : side + a.o_bias_trunk + W + 4 * q4;
                         cnext = *(const f32x4*)v;
@@ -648,6 +813,10 @@ void mlp_f16s_kernel(const Args a) {
                     constexpr int ks = decltype(ks_c)::value, sub = decltype(s_c)::value;
                     if constexpr (t == 0) pack_sched<true, SIN, NT - 1, ks, sub>(ph, pl, pt, dn, up, nup);
                     else pack_sched<false, SOUT, t - 1, ks, sub>(ph, pl, pt, dn, up, nup);
+                    if constexpr (STASH && ks == 7 && (sub == 3 || sub == 4)) {
+                        if constexpr (t == 0) stash_tile<true, true, NT - 1>(pt[2 * (sub - 3)], pt[2 * (sub - 3) + 1], rowp[sub - 3], mw[sub - 3], nib_sh);
+                        else stash_tile<false, false, t - 1>(pt[2 * (sub - 3)], pt[2 * (sub - 3) + 1], rowp[sub - 3], mw[sub - 3], nib_sh);
+                    }
                     if constexpr (ks == 7 && sub == 2) {
                         if constexpr (t + 1 < NT) cnext = *(const f32x4*)(bf + MT * (t + 1));
                         else {                                          // density tile: row 3 = density bias (lane quarter 0 only)
@@ -660,6 +829,11 @@ void mlp_f16s_kernel(const Args a) {
 #pragma unroll
                 for (int p = 0; p < NP; ++p) { ph[p] = ah[p]; pl[p] = al[p]; }
                 cin = cnext;
+                if constexpr (STASH && t == 0) {                 // the trunk's last tile is out: from here on the rows are linear_feat's (no activation)
+                    end_trunk_layer();
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) rowp[p] = a.stash_f + out_idx[p] * W + 4 * q4;
+                }
             });
             // density tile over the trunk output (row 3); packs the feature layer's last tile; reads the direction bias of tile 0
             {
@@ -668,10 +842,16 @@ void mlp_f16s_kernel(const Args a) {
                     constexpr int ks = decltype(ks_c)::value, sub = decltype(s_c)::value;
                     pack_sched<false, SOUT, NT - 1, ks, sub>(ph, pl, pt, dn, up, nup);
                     if constexpr (ks == 7 && (sub == 2 || sub == 3)) cnextd[sub - 2] = *(const f32x4*)(scratch + 4 * q4);
+                    if constexpr (STASH && ks == 7 && (sub == 4 || sub == 5))
+                        stash_tile<false, false, NT - 1>(pt[2 * (sub - 4)], pt[2 * (sub - 4) + 1], rowp[sub - 4], mw[sub - 4], nib_sh);
                 };
                 job<128, KH, BIG, 0>(hdh, hdl, csel1, bh_in, bl_in, aq, smem, ring, lane, hook);
 #pragma unroll
                 for (int p = 0; p < NP; ++p) cind[p] = cnextd[p];
+                if constexpr (STASH) {
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) rowp[p] = a.stash_g + out_idx[p] * (W / 2) + 4 * q4;
+                }
             }
             // view-direction layer: 8 jobs over the feature layer's output; ReLU'd tiles go into fragments 0..3 of set SIN (the
             // trunk output is dead once the density tile has run)
@@ -681,6 +861,8 @@ void mlp_f16s_kernel(const Args a) {
                 auto hook = [&](auto ks_c, auto s_c) __attribute__((always_inline)) {
                     constexpr int ks = decltype(ks_c)::value, sub = decltype(s_c)::value;
                     if constexpr (t > 0) pack_sched<true, SIN, t - 1, ks, sub>(ph, pl, pt, dn, up, nup);
+                    if constexpr (STASH && t > 0 && ks == 6 && (sub == 4 || sub == 5))      // (group 7's gaps carry this layer's own loads)
+                        stash_tile<true, true, t - 1>(pt[2 * (sub - 4)], pt[2 * (sub - 4) + 1], rowp[sub - 4], mw[sub - 4], nib_sh);
                     if constexpr (t == 0 && ks == 7 && sub >= 4)            // the density tile finished >= 40 MFMAs ago: keep its one useful value
                         asm volatile("v_fma_f32 %0, %1, %3, %2" : "=v"(dens[sub - 4]) : "v"(hdl[sub - 4][3]), "v"(hdh[sub - 4][3]), "s"(dn));
                     if constexpr (t == 2 && ks == 7 && sub == 3) load_inputs(it + 1 < a.n_iter ? it + 1 : it);      // next unit's ray and depths
@@ -699,11 +881,15 @@ void mlp_f16s_kernel(const Args a) {
             // colour tile over the view-direction output (rows 0..2): 4 k-steps; the last direction tile (second half of fragment 3) is
             // packed in its first group, a whole pair per gap (it feeds k-step 3)
             {
+                PairTmp pt[4];
                 auto hook = [&](auto ks_c, auto s_c) __attribute__((always_inline)) {
                     constexpr int ks = decltype(ks_c)::value, sub = decltype(s_c)::value;
-                    if constexpr (ks == 0 && sub >= 2) pack_pair_block<true, SIN, NT / 2 - 1, sub - 2>(ph, pl, dn, up, nup);
+                    if constexpr (ks == 0 && sub >= 2) pack_pair_block<true, SIN, NT / 2 - 1, sub - 2>(ph, pl, pt, dn, up, nup);
+                    if constexpr (STASH && ks == 1 && (sub == 2 || sub == 3))
+                        stash_tile<true, true, NT / 2 - 1>(pt[2 * (sub - 2)], pt[2 * (sub - 2) + 1], rowp[sub - 2], mw[sub - 2], nib_sh);
                 };
                 job<200, KH / 2, TAIL_USED_P, TAIL_PAIRS - TAIL_USED_P>(hch, hcl, cselh, bh_in, bl_in, aq, smem, ring, lane, hook);
+                if constexpr (STASH) finish_masks<2>(mw, a.mask_g + (size_t)tile_cur * 128, col, q4, tile_active);
             }
             // the MFMAs are asm statements: hipcc does not know that the colour tile is still in flight (XDL write -> VALU read)
             asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
@@ -725,8 +911,9 @@ void mlp_f16s_kernel(const Args a) {
 
 }  // namespace f16s
 
-int mlp_rays_f16s(const mi_nerf_net* net, const void* packed_dev, const float* rays_dev, const float* z_dev, int64_t n_rays, int S,
-                  float* raw_dev, hipStream_t st) {
+struct StashF16s { float* h; float* f; float* g; unsigned* mask_h; unsigned* mask_g; };
+static int launch_f16s(const mi_nerf_net* net, const void* packed_dev, const float* rays_dev, const float* z_dev, int64_t n_rays, int S,
+                       float* raw_dev, const StashF16s* stash, hipStream_t st) {
     using namespace f16s;
     if (int rc = check_net(net)) return rc;
     MN_CHECK_ARG(n_rays >= 0 && S >= 1, "bad sizes n_rays=%lld S=%d", (long long)n_rays, S);
@@ -747,8 +934,8 @@ int mlp_rays_f16s(const mi_nerf_net* net, const void* packed_dev, const float* r
     a.o_bias_trunk = L.bias_trunk; a.o_bias_feat = L.bias_feat; a.o_bias_d = L.bias_d; a.o_head_b = L.head_b; a.o_wdir_t = L.wdir_t;
     const size_t lds = RING_BYTES_S + (size_t)a.side_floats * 4 + 4 * (256 / 2) * 4 + (size_t)4 * 2 * NP * KPE * QUAD_BYTES;
     MN_CHECK_ARG(lds <= 160 * 1024, "LDS budget exceeded: %zu bytes", lds);
-    static LdsOptIn opt_in = {};
-    if (int rc = ensure_lds_opt_in(opt_in, (const void*)mlp_f16s_kernel)) return rc;
+    static LdsOptIn opt_in = {}, opt_in_stash = {};
+    if (int rc = stash ? ensure_lds_opt_in(opt_in_stash, (const void*)mlp_f16s_kernel<true>) : ensure_lds_opt_in(opt_in, (const void*)mlp_f16s_kernel<false>)) return rc;
     const int n_cus = device_cus();
     const long long n_wg = (n_wtiles + 3) / 4;
     const int grid = (int)(n_wg < n_cus ? n_wg : n_cus);
@@ -756,9 +943,27 @@ int mlp_rays_f16s(const mi_nerf_net* net, const void* packed_dev, const float* r
     const long long it_flat = (n_wtiles + NW - 1) / NW, it_ray = (((long long)n_rays + NW - 1) / NW) * a.tpr;
     if ((long long)n_rays >= NW && it_ray <= it_flat) { a.ppr = (unsigned)a.tpr; a.n_iter = (unsigned)it_ray; }      // ray-major: whole rays per wave
     else { a.ppr = 0; a.n_iter = (unsigned)it_flat; }
-    hipLaunchKernelGGL(mlp_f16s_kernel, dim3(grid), dim3(256), lds, st, a);
+    if (stash) {
+        a.stash_h = stash->h; a.stash_f = stash->f; a.stash_g = stash->g; a.mask_h = stash->mask_h; a.mask_g = stash->mask_g;
+        a.stash_rows = (long long)n_rays * S;
+        hipLaunchKernelGGL(mlp_f16s_kernel<true>, dim3(grid), dim3(256), lds, st, a);
+    } else {
+        hipLaunchKernelGGL(mlp_f16s_kernel<false>, dim3(grid), dim3(256), lds, st, a);
+    }
     MN_LAUNCH_CHECK("mlp_f16s_kernel");
     return MI_NERF_OK;
+}
+int mlp_rays_f16s(const mi_nerf_net* net, const void* packed_dev, const float* rays_dev, const float* z_dev, int64_t n_rays, int S,
+                  float* raw_dev, hipStream_t st) {
+    return launch_f16s(net, packed_dev, rays_dev, z_dev, n_rays, S, raw_dev, nullptr, st);
+}
+// training forward in split precision: the same outputs plus the activation stash of mlp_rays_fp32_stash (same tensors, same layouts:
+// the backward pass does not know which forward ran)
+int mlp_rays_f16s_stash(const mi_nerf_net* net, const void* packed_dev, const float* rays_dev, const float* z_dev, int64_t n_rays, int S,
+                        float* raw_dev, float* stash_h, float* stash_f, float* stash_g, unsigned* mask_h, unsigned* mask_g, hipStream_t st) {
+    MN_CHECK_ARG(stash_h && stash_f && stash_g && mask_h && mask_g, "NULL stash pointer");
+    const StashF16s sp{stash_h, stash_f, stash_g, mask_h, mask_g};
+    return launch_f16s(net, packed_dev, rays_dev, z_dev, n_rays, S, raw_dev, &sp, st);
 }
 
 }  // namespace minerf

@@ -385,7 +385,7 @@ def train(idx, i_train, images, gt_cam_param, hw, model, criterion, posenc, opti
         pose = torch.as_tensor(np.asarray(gt_extrinsic[i_img]) if not isinstance(gt_extrinsic, torch.Tensor) else gt_extrinsic[i_img])
         rays_o, rays_d, target_img = sample_rays_and_pixel(idx, img_w, img_h, gt_intrinsic, pose[:3, :4], target_full, opts, generator)
     rgb_c, _, rgb_f, _ = NP.batchify_rays_and_render_by_chunk(rays_o.contiguous(), rays_d.contiguous(), model, posenc, img_h, img_w,
-                                                              gt_intrinsic, opts)                # train.py:53
+                                                              gt_intrinsic, opts, **_precision(opts))      # train.py:53
     optimizer.zero_grad()
     target_img = target_img.contiguous()
     loss = criterion(rgb_c, target_img)                                                       # train.py:60

@@ -190,11 +190,11 @@ def render_rays(rays, model, posenc, opts, *, t_rand=None, u=None, seed=None, ra
     sequence.  Returns ``{'rgb_c','disp_c'[,'rgb_f','disp_f']}``.  ``bf16`` / ``f16s`` select the network's precision mode
     (fp32 MFMA by default; bf16 MFMA; f16 split precision: fp32-grade results on the f16 matrix pipe)."""
     if train_path.wants_grad(model):
-        if bf16 or f16s or return_intermediates:
-            raise MiNerfError("the training path is fp32 and returns no intermediates")
+        if bf16 or return_intermediates:
+            raise MiNerfError("the training path has no bf16 mode (fp32, or f16s=True: split-precision forward) and returns no intermediates")
         if rays.dim() != 2 or rays.shape[1] != 6:
             raise MiNerfError(f"rays must be [n, 6] (o, d), got {tuple(rays.shape)}")
-        return train_path.render_train(rays, model, opts, t_rand=t_rand, u=u, seed=_next_seed(seed), ray_offset=int(ray_offset))
+        return train_path.render_train(rays, model, opts, t_rand=t_rand, u=u, seed=_next_seed(seed), ray_offset=int(ray_offset), f16s=f16s)
     packed = packed_for(model)
     rays = as_f32_dev(rays, packed.device)
     if rays.dim() != 2 or rays.shape[1] != 6:
@@ -211,8 +211,8 @@ def batchify_rays_and_render_by_chunk(ray_o, ray_d, model, posenc, H, W, K, opts
     registers, so rays are launched in slabs of up to MAX_RAYS_PER_LAUNCH.  The result does not depend on
     the slab size because the jitter is keyed on the global ray index (``ray_offset`` + position)."""
     training = train_path.wants_grad(model)
-    if training and (bf16 or f16s):
-        raise MiNerfError("the training path is fp32")
+    if training and bf16:
+        raise MiNerfError("the training path has no bf16 mode (fp32, or f16s=True: split-precision forward, fp32 backward)")
     packed = None if training else packed_for(model)
     dev = next(model.parameters()).device if training else packed.device
     ray_d = as_f32_dev(ray_d, dev)
@@ -234,7 +234,7 @@ def batchify_rays_and_render_by_chunk(ray_o, ray_d, model, posenc, H, W, K, opts
         tr, uu = (None if t_rand is None else t_rand[i:j]), (None if u is None else u[i:j])
         if training:                                                # train.py:53-54: one autograd node per slab
             parts.append(train_path.render_train(rays[i:j].contiguous(), model, opts, t_rand=tr, u=uu, seed=seed,
-                                                 ray_offset=int(ray_offset) + i))
+                                                 ray_offset=int(ray_offset) + i, f16s=f16s))
         else:
             parts.append(_render(rays[i:j], packed, opts, tr, uu, seed, int(ray_offset) + i, bf16, False, f16s))
     def cat(key):

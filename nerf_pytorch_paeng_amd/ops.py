@@ -349,8 +349,35 @@ def pack_apply_bf16(net: Net, map_dev: torch.Tensor, flat: torch.Tensor) -> torc
     return out
 
 
-def mlp_rays_train(net: Net, packed: torch.Tensor, rays: torch.Tensor, z: torch.Tensor, stash: Optional[torch.Tensor] = None):
-    """Training forward: raw [n,S,4] plus the activation stash the backward reads."""
+def pack_map_f16s(net: Net) -> torch.Tensor:
+    """Gather map (CPU int32) from the flat parameter vector to the split-precision blob: stream elements (the source weight at its hi and
+    at its lo position), then side-table floats."""
+    n = lib().mi_nerf_pack_map_f16s_len(C.byref(net))
+    if n == 0:
+        check(1, "mi_nerf_pack_map_f16s_len")
+    m = torch.empty(n, dtype=torch.int32)
+    check(lib().mi_nerf_pack_map_f16s(C.byref(net), m.data_ptr(), m.numel()), "mi_nerf_pack_map_f16s")
+    return m
+
+
+def pack_apply_f16s(net: Net, map_dev: torch.Tensor, flat: torch.Tensor, out_of_range: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Device-side pack of the split-precision blob (uint8) from the flat parameter vector.  ``out_of_range`` (uint32 [1] on the device, or
+    None) counts stream elements whose weight is NaN or beyond the f16 range -- the host packer refuses those."""
+    dev = flat.device
+    nbytes = lib().mi_nerf_packed_bytes_f16s(C.byref(net))
+    if nbytes == 0:
+        check(1, "mi_nerf_packed_bytes_f16s")
+    out = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    with _guard(dev):
+        check(lib().mi_nerf_pack_apply_f16s(C.byref(net), dev_ptr(map_dev, "map", torch.int32), dev_ptr(flat, "flat"), dev_ptr(out, "blob", torch.uint8, 16),
+                                            nbytes, None if out_of_range is None else dev_ptr(out_of_range, "out_of_range", torch.int32), stream_ptr(dev)),
+              "mi_nerf_pack_apply_f16s")
+    return out
+
+
+def mlp_rays_train(net: Net, packed: torch.Tensor, rays: torch.Tensor, z: torch.Tensor, stash: Optional[torch.Tensor] = None, f16s: bool = False):
+    """Training forward: raw [n,S,4] plus the activation stash the backward reads.  ``f16s``: the forward runs in split precision (``packed``
+    from pack_apply_f16s / pack_module(..., f16s=True)); the stash has the same tensors in the same layouts either way."""
     n, S = z.shape
     if tuple(rays.shape) != (n, 6):
         raise MiNerfError(f"rays must be [n,6], got {tuple(rays.shape)}")
@@ -359,9 +386,10 @@ def mlp_rays_train(net: Net, packed: torch.Tensor, rays: torch.Tensor, z: torch.
         stash = torch.empty(lay.stash_bytes, dtype=torch.uint8, device=z.device)
     raw = torch.empty(n, S, 4, dtype=torch.float32, device=z.device)
     with _guard(z.device):
-        check(lib().mi_nerf_mlp_rays_train(C.byref(net), dev_ptr(packed, "packed", torch.uint8, 16), dev_ptr(rays, "rays"), dev_ptr(z, "z"), n, S,
-                                           dev_ptr(raw, "raw", align=16), dev_ptr(stash, "stash", torch.uint8, 16), stash.numel(),
-                                           stream_ptr(z.device)), "mi_nerf_mlp_rays_train")
+        fn = lib().mi_nerf_mlp_rays_train_f16s if f16s else lib().mi_nerf_mlp_rays_train
+        check(fn(C.byref(net), dev_ptr(packed, "packed", torch.uint8, 16), dev_ptr(rays, "rays"), dev_ptr(z, "z"), n, S,
+                 dev_ptr(raw, "raw", align=16), dev_ptr(stash, "stash", torch.uint8, 16), stash.numel(),
+                 stream_ptr(z.device)), "mi_nerf_mlp_rays_train_f16s" if f16s else "mi_nerf_mlp_rays_train")
     return raw, stash
 
 

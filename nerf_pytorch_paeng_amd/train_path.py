@@ -37,6 +37,15 @@ class _TrainState:
         self.names = ops.param_names(self.net)
         self.map_fwd = ops.pack_map(self.net, False).to(device)
         self.map_bwd = ops.pack_map(self.net, True).to(device)
+        self._map_f16s = None
+        self.f16s_out_of_range = None          # device counter: weights the split-precision packer could not represent (NaN / beyond f16)
+
+    def map_f16s(self) -> torch.Tensor:
+        """Gather map of the split-precision blob, built on first use (f16s=True training forward)."""
+        if self._map_f16s is None:
+            self._map_f16s = ops.pack_map_f16s(self.net).to(self.device)
+            self.f16s_out_of_range = torch.zeros(1, dtype=torch.int32, device=self.device)
+        return self._map_f16s
 
     def params(self, module: torch.nn.Module) -> List[torch.Tensor]:
         named = dict(module.named_parameters())
@@ -77,10 +86,19 @@ class _RenderTrain(torch.autograd.Function):
         n_each = len(st.names)
         net = st.net
         Sc, Nf, det = cfg["Sc"], cfg["Nf"], cfg["det"]
+        f16s = bool(cfg.get("f16s", False))
+
+        def forward_net(flat, blob, z):
+            # f16s: the forward launch runs in split precision (fp32-grade outputs and stash; blob re-packed on the device like the fp32
+            # one); the backward is the same fp32 kernels either way and keeps reading the fp32 blob's side tables
+            if f16s:
+                return ops.mlp_rays_train(net, ops.pack_apply_f16s(net, st.map_f16s(), flat, st.f16s_out_of_range), rays, z, f16s=True)
+            return ops.mlp_rays_train(net, blob, rays, z)
+
         flat_c = _flat(params[:n_each])
         blob_c = ops.pack_apply(st.map_fwd, flat_c)
         z_c = ops.stratified_z(cfg["near"], cfg["far"], t_rand) if z_override is None else z_override[0]
-        raw_c, stash_c = ops.mlp_rays_train(net, blob_c, rays, z_c)
+        raw_c, stash_c = forward_net(flat_c, blob_c, z_c)
         rgb_c, disp_c, _, w_c, _ = ops.composite(raw_c, z_c, rays, want_all=True)
         ctx.st, ctx.Nf = st, Nf
         saved = [rays, flat_c, blob_c, z_c, raw_c, stash_c]
@@ -88,7 +106,7 @@ class _RenderTrain(torch.autograd.Function):
             flat_f = _flat(params[n_each:])
             blob_f = ops.pack_apply(st.map_fwd, flat_f)
             z_f = ops.fine_z(z_c, w_c, Nf, det, None if det else u) if (z_override is None or z_override[1] is None) else z_override[1]
-            raw_f, stash_f = ops.mlp_rays_train(net, blob_f, rays, z_f)
+            raw_f, stash_f = forward_net(flat_f, blob_f, z_f)
             rgb_f, disp_f, *_ = ops.composite(raw_f, z_f, rays, want_all=False)
             saved += [flat_f, blob_f, z_f, raw_f, stash_f]
         else:
@@ -157,9 +175,12 @@ class _EmbeddedTrain(torch.autograd.Function):
 
 
 def render_train(rays: torch.Tensor, model: torch.nn.Module, opts, *, t_rand=None, u=None, seed: int = 0, ray_offset: int = 0,
-                 z_override=None, det: Optional[bool] = None) -> Dict[str, torch.Tensor]:
-    """Differentiable ``render_rays`` (nerf_process.py:185-216) for one slab of rays [n, 6]."""
+                 z_override=None, det: Optional[bool] = None, f16s: bool = False) -> Dict[str, torch.Tensor]:
+    """Differentiable ``render_rays`` (nerf_process.py:185-216) for one slab of rays [n, 6].  ``f16s``: the two forward launches run in
+    split precision (fp32-grade results, ~3x faster); the backward kernels are the fp32 ones."""
     st = _state_for(model)
+    if f16s and st.net.W != 256:
+        raise MiNerfError(f"the split-precision forward is built for netWidth 256 (got {st.net.W})")
     dev = st.device
     if isinstance(rays, torch.Tensor) and rays.requires_grad:
         raise MiNerfError("rays require grad: the training path differentiates w.r.t. the MLP parameters only (the reference trains "
@@ -175,7 +196,7 @@ def render_train(rays: torch.Tensor, model: torch.nn.Module, opts, *, t_rand=Non
         u = ops.fill_uniform(seed, 1, ray_offset, n, Nf, dev) if u is None else as_f32_dev(u, dev)
     else:
         u = None
-    cfg = {"near": float(opts.near), "far": float(opts.far), "Sc": Sc, "Nf": Nf, "det": bool(det)}
+    cfg = {"near": float(opts.near), "far": float(opts.far), "Sc": Sc, "Nf": Nf, "det": bool(det), "f16s": bool(f16s)}
     params = st.params(model.model_coarse) + st.params(model.model_fine)
     rgb_c, disp_c, rgb_f, disp_f = _RenderTrain.apply(st, rays, cfg, t_rand, u, z_override, *params)
     out = {"rgb_c": rgb_c, "disp_c": disp_c}

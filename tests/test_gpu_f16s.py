@@ -157,3 +157,114 @@ def test_eval_harness_in_split_precision(tmp_path):
         assert diff.max() <= 1 and (diff > 0).mean() < 0.02
     with pytest.raises(ValueError):
         harness.test(0, [0], posenc, model, gt, K, poses.to(DEV), (Hs, Ws), make_opts(N_samples_c=32, N_samples_f=32, precision="fp8"))
+
+
+# ---------------------------------------------------------------------------------------------------
+# training forward in split precision (mi_nerf_mlp_rays_train_f16s): same stash, same layouts as the fp32 one
+# ---------------------------------------------------------------------------------------------------
+def _flat_params(sd, prefix, net):
+    return torch.cat([torch.as_tensor(sd[prefix + k]).reshape(-1) for k in ops.param_names(net)]).float().to(DEV)
+
+
+@pytest.mark.parametrize("D,skip", [(8, 4), (4, -1), (3, 0)])
+def test_f16s_device_pack_is_the_host_pack(D, skip):
+    sd = synthetic.make_state_dict(5, D, 256, skips=() if skip < 0 else (skip,))
+    net = weights.infer_net(sd)
+    assert (net.D, net.W, net.skip) == (D, 256, skip)
+    host = ops.pack_module(sd, "model_fine.", net, f16s=True)
+    m = ops.pack_map_f16s(net).to(DEV)
+    bad = torch.zeros(1, dtype=torch.int32, device=DEV)
+    dev = ops.pack_apply_f16s(net, m, _flat_params(sd, "model_fine.", net), bad)
+    assert torch.equal(dev.cpu(), host) and int(bad) == 0
+    flat = _flat_params(sd, "model_fine.", net)
+    flat[7] = 1e6                                                   # beyond f16: counted, not refused (the step cannot stop for a host check)
+    ops.pack_apply_f16s(net, m, flat, bad)
+    assert int(bad) > 0
+
+
+@pytest.mark.parametrize("n,S", [(300, 64), (77, 65), (64, 192)])
+def test_f16s_training_forward_leaves_the_fp32_stash(n, S, lego_rays):
+    """Same raw outputs (fp32 grade), same activation rows, same ReLU' bits in the backward kernel's own lane order: the masks may differ
+    only where a pre-activation is within rounding of zero."""
+    sd = synthetic.make_state_dict(3, 8, 256)
+    net = weights.infer_net(sd)
+    rays = lego_rays[:n].contiguous()
+    z = torch.sort(torch.rand(n, S, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1)) * 4 + 2, -1)[0]
+    blob32 = ops.pack_module(sd, "model_fine.", net).to(DEV)
+    blob16 = ops.pack_module(sd, "model_fine.", net, f16s=True).to(DEV)
+    raw32, st32 = ops.mlp_rays_train(net, blob32, rays, z)
+    lay = ops.train_layout(net, n, S)
+    st16 = torch.full((lay.stash_bytes,), 0xCD, dtype=torch.uint8, device=DEV)          # poison: every byte the backward reads must be written
+    raw16, st16 = ops.mlp_rays_train(net, blob16, rays, z, stash=st16, f16s=True)
+    torch.cuda.synchronize()
+    assert float((raw16 - raw32).abs().max()) < 2e-5 * float(raw32.abs().max())
+    P, W, Dn = n * S, 256, net.D
+    ntile = n * ((S + 31) // 32)
+
+    def view(st, off, count, dtype):
+        return st[off:off + count * 4].view(dtype)
+
+    for name, off, cnt in (("stash_h", lay.stash_h, Dn * P * W), ("stash_f", lay.stash_f, P * W), ("stash_g", lay.stash_g, P * W // 2)):
+        a, b = view(st32, off, cnt, torch.float32), view(st16, off, cnt, torch.float32)
+        assert torch.isfinite(b).all(), name
+        assert float((a - b).abs().max()) < 2e-5 * float(a.abs().max()), name
+    # masks: bit-identical except where the fp32 kernel's pre-activation sits within rounding of zero
+    for name, off, words, rows in (("mask_h", lay.mask_h, Dn * ntile * 64 * 4, None), ("mask_g", lay.mask_g, ntile * 64 * 2, None)):
+        a, b = view(st32, off, words, torch.int32), view(st16, off, words, torch.int32)
+        diff = (a ^ b)
+        nbits = sum(int(((diff >> k) & 1).sum()) for k in range(32))
+        assert nbits <= 2e-4 * words * 32, (name, nbits, words * 32)
+    # ... and where they differ the stashed activation is (near) zero on both sides: rebuild the fp32 kernel's bit order for layer 0 of stash_h
+    h32 = view(st32, lay.stash_h, P * W, torch.float32).reshape(n, S, W)
+    m16 = view(st16, lay.mask_h, ntile * 64 * 4, torch.int32).reshape(n, (S + 31) // 32, 64, 4)
+    tpr = (S + 31) // 32
+    f = torch.arange(W, device=DEV)
+    hh, word, bit = (f >> 2) & 1, f >> 6, 31 - (4 * ((f >> 3) & 7) + (f & 3))
+    for chunk in range(tpr):
+        j = torch.arange(min(32, S - 32 * chunk), device=DEV)
+        lanes = j[:, None] + 32 * hh[None, :]                                           # [points, features] -> lane of the backward kernel
+        got = (m16[:, chunk][:, lanes, word[None, :].expand_as(lanes)] >> bit[None, :]) & 1
+        want = (h32[:, 32 * chunk + j] > 0).to(torch.int32)
+        wrong = got != want
+        assert float(wrong.float().mean()) < 2e-4
+        assert float(h32[:, 32 * chunk + j][wrong].abs().max() if wrong.any() else 0.0) < 1e-5
+
+
+def test_f16s_training_step_gradients_match_the_fp32_path(lego_rays):
+    """loss.backward() through the split-precision forward against the fp32 path's on the same rays and depths; an optimizer step goes
+    through; bf16 training is refused."""
+    from nerf_pytorch_paeng_amd import train_path
+    from nerf_pytorch_paeng_amd.model import NeRF
+    sd = synthetic.make_state_dict(11, 8, 256)
+    n, Sc, Nf = 256, 64, 128
+    rays = lego_rays[:n].contiguous()
+    opts = make_opts(perturb=1.0)
+    g = torch.Generator(device=DEV).manual_seed(3)
+    z_c = torch.sort(torch.rand(n, Sc, device=DEV, generator=g) * 4 + 2, -1)[0]
+    z_f = torch.sort(torch.rand(n, Sc + Nf, device=DEV, generator=g) * 4 + 2, -1)[0]
+    target = torch.rand(n, 3, device=DEV, generator=g)
+    grads = {}
+    for mode in (False, True):
+        model = NeRF(8, 256, 63, 27).to(DEV)
+        model.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+        out = train_path.render_train(rays, model, opts, z_override=(z_c, z_f), f16s=mode)
+        loss = ((out["rgb_c"] - target) ** 2).mean() + ((out["rgb_f"] - target) ** 2).mean()
+        loss.backward()
+        grads[mode] = {k: p.grad.clone() for k, p in model.named_parameters()}
+        if mode:
+            torch.optim.Adam(model.parameters(), lr=5e-4).step()
+            st = train_path._state_for(model)
+            assert int(st.f16s_out_of_range) == 0
+    for k in grads[False]:
+        a, b = grads[False][k], grads[True][k]
+        assert torch.isfinite(b).all(), k
+        # the fine network's trunk gradients on such batches are sums that almost cancel (terms a hundred times the result): two fp32-grade
+        # forwards land 1e-4 .. 2e-3 apart there, like the reference's own fp32 result and an fp64 evaluation (DESIGN.md section 8; the F11
+        # test holds both forwards to that fp64 yardstick).  Everything else -- every coarse tensor, the heads, linear_feat / linear_d -- agrees
+        # to fp32 rounding (observed <= 8e-7).
+        ill = k.startswith("model_fine.linear_x.")
+        assert float((a - b).abs().max()) <= (6e-3 if ill else 5e-6) * float(a.abs().max()), (k, float((a - b).abs().max()), float(a.abs().max()))
+        assert float((a - b).norm()) <= (1.5e-3 if ill else 5e-6) * float(a.norm()), k
+    model = NeRF(8, 256, 63, 27).to(DEV)
+    with pytest.raises(MiNerfError):
+        NP.render_rays(rays, model, None, opts, bf16=True)

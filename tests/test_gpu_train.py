@@ -547,10 +547,11 @@ def test_model_forward_is_differentiable_like_the_reference_module(D, W, skip, n
         assert all(p.grad is None for p in other.parameters())
 
 
-@pytest.mark.parametrize("tag", ["d8w256", "d4w128"])
-def test_F11_backward_matches_the_reference_training_step(golden, tag):
+@pytest.mark.parametrize("tag,f16s", [("d8w256", False), ("d4w128", False), ("d8w256", True)])
+def test_F11_backward_matches_the_reference_training_step(golden, tag, f16s):
     """The HIP backward against the gradients of the reference's OWN loss.backward() (fixture F11: train.py:53-70 executed by
-    oracle/gen_fixtures.py on 64 rays with injected randoms).  Depths are pinned to the ones the reference sampled."""
+    oracle/gen_fixtures.py on 64 rays with injected randoms).  Depths are pinned to the ones the reference sampled.
+    ``f16s``: the same bars with the two forward launches in split precision (fp32-grade outputs and stash; the backward is unchanged)."""
     from nerf_pytorch_paeng_amd import train_path
     from nerf_pytorch_paeng_amd.model import NeRF
     from types import SimpleNamespace
@@ -564,7 +565,7 @@ def test_F11_backward_matches_the_reference_training_step(golden, tag):
     rays = torch.from_numpy(golden("F8_render_rays")["legoA_rays"]).to(DEV).contiguous()
     opts = SimpleNamespace(near=2.0, far=6.0, N_samples_c=Sc, N_samples_f=Nf, perturb=1.0)
     t_rand, u = torch.from_numpy(R.counter_uniform(0, 0, 0, 64, Sc)).to(DEV), torch.from_numpy(R.counter_uniform(0, 1, 0, 64, Nf)).to(DEV)
-    out = train_path.render_train(rays, model, opts, t_rand=t_rand, u=u,
+    out = train_path.render_train(rays, model, opts, t_rand=t_rand, u=u, f16s=f16s,
                                   z_override=(torch.from_numpy(g[f"{tag}_z_c"]).to(DEV), torch.from_numpy(g[f"{tag}_z_f"]).to(DEV)))
     tgt = torch.from_numpy(g[f"{tag}_target"]).to(DEV)
     loss_c, loss_f = torch.mean((out["rgb_c"] - tgt) ** 2), torch.mean((out["rgb_f"] - tgt) ** 2)          # train.py:60-66
@@ -590,4 +591,5 @@ def test_F11_backward_matches_the_reference_training_step(golden, tag):
         assert rel_err(p.grad, want) <= 4.0 * e_ref + 2e-5, (k, rel_err(p.grad, want), e_ref)
         n += 1
     assert n == (48 if D == 8 else 32)
-    print(f"F11 {tag}: worst per-tensor gradient error vs the fp64-MLP evaluation {worst:.2e} (the reference's own: {worst_ref:.2e})")
+    print(f"F11 {tag}{' (split-precision forward)' if f16s else ''}: worst per-tensor gradient error vs the fp64-MLP evaluation {worst:.2e} "
+          f"(the reference's own: {worst_ref:.2e})")
