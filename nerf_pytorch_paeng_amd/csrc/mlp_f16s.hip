@@ -466,6 +466,9 @@ __device__ __forceinline__ void pack_pair_block(const f32x4 (&ph)[NP], const f32
 // f >> 6 (mlp_core.h mask_pack_chunk).  Here lane (q4, col) of point tile p holds f = 16 T + 4 q4 + i: hh = q4 & 1, word T >> 2, nibble
 // (2 T + (q4 >> 1)) & 7 counted from the top.  Lanes q4 and q4 ^ 2 (lane ^ 32) fill alternate nibbles of the same words: the layer's
 // words are OR-ed across that pair once, at the end (finish_masks).
+#ifndef MN_F16S_STOREFLAGS
+#define MN_F16S_STOREFLAGS "nt sc1"
+#endif
 template <bool RELU, bool MASK, int T>
 __device__ __forceinline__ void stash_tile(const PairTmp& e0, const PairTmp& e1, float* rowp, unsigned (&mw)[4], unsigned nib_sh) {
     f32x4 v;
@@ -475,7 +478,11 @@ __device__ __forceinline__ void stash_tile(const PairTmp& e0, const PairTmp& e1,
         asm volatile("v_max_f32 %0, 0, %1" : "=v"(v[2]) : "v"(e1.y0));
         asm volatile("v_max_f32 %0, 0, %1" : "=v"(v[3]) : "v"(e1.y1));
     } else { v[0] = e0.y0; v[1] = e0.y1; v[2] = e1.y0; v[3] = e1.y1; }
-    *(f32x4*)(rowp + MT * T) = v;
+    // streaming stores: the rows are read next by another kernel, and as ordinary stores they cost this kernel 1.4 ms of 3.6 (the L2
+    // allocates a line per 64-byte piece); A/B on one box: default 3.62 ms, nt 2.98, nt sc1 2.84, sc1 4.02, sc0 sc1 4.13, no stores 2.21
+    // (an asm statement: hipcc does not see a store here, so the wait states it would put between a 128-bit store and a VALU write of
+    // the data registers are ours to add -- without them the next instruction's result went to memory instead of the activation)
+    asm volatile("global_store_dwordx4 %0, %1, off offset:%2 " MN_F16S_STOREFLAGS "\n\ts_nop 1" ::"v"(rowp), "v"(v), "n"(MT * T * 4) : "memory");
     if constexpr (MASK) {
         unsigned b[4];
 #pragma unroll
