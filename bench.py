@@ -464,8 +464,8 @@ def worker(args) -> None:
         target = torch.rand(N_RAYS, 3, generator=torch.Generator().manual_seed(rank)).to(dev)
         NP.manual_seed(0)
 
-        def train_step():
-            rgb_c, _, rgb_f, _ = NP.batchify_rays_and_render_by_chunk(weak.o, weak.d, model, posenc, H, W, K, opts, ray_offset=rank * N_RAYS)
+        def train_step(f16s=False):
+            rgb_c, _, rgb_f, _ = NP.batchify_rays_and_render_by_chunk(weak.o, weak.d, model, posenc, H, W, K, opts, ray_offset=rank * N_RAYS, f16s=f16s)
             optim.zero_grad()
             loss = torch.nn.functional.mse_loss(rgb_c, target) + torch.nn.functional.mse_loss(rgb_f, target)   # train.py:60-66
             loss.backward()
@@ -490,6 +490,24 @@ def worker(args) -> None:
                  "peak_mem_GiB": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
                  "what": "batchify_rays_and_render_by_chunk (grad) + MSE(rgb_c)+MSE(rgb_f) + loss.backward() + Adam.step(), "
                          f"{N_RAYS} rays per GPU, each rank an independent replica (the reference has no data-parallel training)"}
+        # the same step with the two FORWARD launches in split precision (fp32-grade outputs and activation stash; the backward kernels are the
+        # fp32 ones): an extra leg, like f16_split for inference -- ms_per_step / frac above stay the all-fp32-MFMA step's
+        if not args.no_f16s_leg:
+            for _ in range(2):
+                train_step(True)
+            torch.cuda.synchronize(dev)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(train_steps):
+                loss = train_step(True)
+            torch.cuda.synchronize(dev)
+            barrier()
+            ts_ms = 1e3 * max_over_ranks(time.perf_counter() - t0) / train_steps
+            assert torch.isfinite(loss).all()
+            train["f16_split_forward"] = {"ms_per_step": round(ts_ms, 3), "rays_per_s": round(world * N_RAYS / (ts_ms * 1e-3), 1),
+                                          "speedup_vs_f32_step": round(t_ms / ts_ms, 3),
+                                          "what": "forward launches by mlp_f16s_kernel<STASH> (f16 hi + lo operands, fp32 accumulate), backward unchanged; "
+                                                  "gradients within the fp32 path's bars of an fp64 evaluation (tests/test_gpu_train.py F11, f16s case)"}
         # roofline leg of the training kernels' GEMM: the 256x256 weight-gradient products over the fine net's 786 432 points, as the
         # backward pass runs them (nine in one launch: mi_nerf_wgrad_products), and one product launched on its own
         n_pts = N_RAYS * (SC + NF)

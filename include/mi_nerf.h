@@ -246,6 +246,13 @@ int mi_nerf_mlp_rays_train(const mi_nerf_net* net, const void* packed_dev, const
 int mi_nerf_mlp_backward(const mi_nerf_net* net, const void* packed_dev, const void* packed_bwd_dev, const float* rays_dev,
                          const float* z_dev, int64_t n_rays, int S, const float* d_raw_dev, const void* stash_dev,
                          void* work_dev, size_t work_bytes, float* grads_dev, int stage, void* stream);
+/* ... with a mode: bit 0 = the nine W-wide weight-gradient products of a network in SPLIT PRECISION (operands converted on the fly to
+ * f16 hi + lo pairs, three f16 MFMAs per product into one fp32 accumulator, the gradient operand scaled by a power of two taken from
+ * max|d_raw| on the device): fp32-grade gradients, the products bound by their HBM reads instead of the fp32 matrix rate.  mode 0 is
+ * mi_nerf_mlp_backward. */
+int mi_nerf_mlp_backward_mode(const mi_nerf_net* net, const void* packed_dev, const void* packed_bwd_dev, const float* rays_dev,
+                              const float* z_dev, int64_t n_rays, int S, const float* d_raw_dev, const void* stash_dev, void* work_dev,
+                              size_t work_bytes, float* grads_dev, int stage, int mode, void* stream);
 
 /* The same pair for pre-embedded rows x [n, in_x + in_d]: what autograd does when model(embedded, is_fine) is called directly
  * with gradients enabled, as the reference's own render_rays does (nerf_process.py:190-192,206-207; model/NeRF.py:70-78) --

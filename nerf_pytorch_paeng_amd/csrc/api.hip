@@ -70,7 +70,7 @@ int wgrad_products(int, const float* const*, const int*, const int*, const float
 int mlp_rays_fp32_stash(const mi_nerf_net*, const void*, const float*, const float*, int64_t, int, float*, float*, float*, float*, unsigned*,
                         unsigned*, hipStream_t);
 int mlp_backward_fp32(const mi_nerf_net*, const void*, const void*, const float*, const float*, int64_t, int, const float*, const void*, void*,
-                      size_t, float*, int, hipStream_t, const float*, int64_t);
+                      size_t, float*, int, hipStream_t, const float*, int64_t, int);
 int mlp_embedded_fp32_stash(const mi_nerf_net*, const void*, const float*, int64_t, float*, float*, float*, float*, unsigned*, unsigned*,
                             hipStream_t);
 int train_layout(const mi_nerf_net*, int64_t, int, mi_nerf_train_layout*);
@@ -327,7 +327,14 @@ int mi_nerf_mlp_backward(const mi_nerf_net* net, const void* packed, const void*
                          int64_t n_rays, int S, const float* d_raw, const void* stash, void* work, size_t work_bytes, float* grads,
                          int stage, void* st) {
     if (int rc = check_net_basic(net)) return rc;
-    return mlp_backward_fp32(net, packed, packed_bwd, rays, z, n_rays, S, d_raw, stash, work, work_bytes, grads, stage, (hipStream_t)st, nullptr, -1);
+    return mlp_backward_fp32(net, packed, packed_bwd, rays, z, n_rays, S, d_raw, stash, work, work_bytes, grads, stage, (hipStream_t)st, nullptr, -1, 0);
+}
+int mi_nerf_mlp_backward_mode(const mi_nerf_net* net, const void* packed, const void* packed_bwd, const float* rays, const float* z,
+                              int64_t n_rays, int S, const float* d_raw, const void* stash, void* work, size_t work_bytes, float* grads,
+                              int stage, int mode, void* st) {
+    if (int rc = check_net_basic(net)) return rc;
+    MN_CHECK_ARG((mode & ~1) == 0, "unknown backward mode %d", mode);
+    return mlp_backward_fp32(net, packed, packed_bwd, rays, z, n_rays, S, d_raw, stash, work, work_bytes, grads, stage, (hipStream_t)st, nullptr, -1, mode);
 }
 int mi_nerf_mlp_embedded_train(const mi_nerf_net* net, const void* packed, const float* x, int64_t n, float* out, void* stash, size_t stash_bytes,
                                void* st) {
@@ -348,7 +355,7 @@ int mi_nerf_mlp_embedded_backward(const mi_nerf_net* net, const void* packed, co
     if (n == 0) return MI_NERF_OK;
     MN_CHECK_ARG(x != nullptr, "NULL device pointer");
     return mlp_backward_fp32(net, packed, packed_bwd, nullptr, nullptr, (n + 31) / 32, 32, d_out, stash, work, work_bytes, grads, 0, (hipStream_t)st,
-                             x, n);
+                             x, n, 0);
 }
 
 int mi_nerf_image_metrics(const float* pred, const float* target, int64_t n, float* out2, void* scratch, size_t scratch_bytes, void* st) {

@@ -357,6 +357,169 @@ void wgrad_big_kernel(const WgradArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same products in SPLIT PRECISION (the training step's extra mode, beside mlp_f16s.hip's forward): both operands converted on the
+// fly to f16 pairs v = hi + lo (lo = f16(v - hi), unscaled) and a product taken as hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_f16 into
+// ONE fp32 accumulator -- every f16 x f16 product is exact in fp32, the accumulation is the fp32 kernel's.  A sum over points needs
+// ABSOLUTE accuracy: an operand element carries an error of at most 2^-25 (the f16 subnormal step) however small it is, 2^-22 relative
+// for elements above 2^-3.  Activations are O(1) as they are; the gradient operand is lifted by a power of two s taken from max|d_raw|
+// (absmax_bits, written on the device by absmax_kernel) so that its largest entries sit near 2^8 -- seven binades below the f16 maximum
+// for what the transposed weights add on the way down; FP16_OVFL makes a conversion beyond that saturate instead of producing inf.  The
+// result is scaled back by 1 / s (exact) on the way out.  Same workgroup shape, operand bijection, slices, partials and reduction as
+// wgrad_big_kernel; a k-step is 16 points (lane half kh takes rows 8 kh .. 8 kh + 7 as the eight k-values of its 128-bit operand), loaded
+// in units of 8 rows, four units (two k-steps, 32 KiB per wave) in flight.  At three times the fp32 matrix rate the kernel is bound by the
+// HBM reads of its operands.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long long n, unsigned* __restrict__ out_bits) {
+    float m = 0.0f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) m = __builtin_fmaxf(m, __builtin_fabsf(x[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m == m) atomicMax(out_bits, __float_as_uint(m));      // non-negative floats order like their bit patterns
+}
+// two fp32 values -> a packed f16 pair hi and the packed pair lo = f16(v * s - hi); S: scale by s first (gradient operand)
+template <bool S>
+__device__ __forceinline__ void split_pair(float v0, float v1, float s, unsigned& hi, unsigned& lo) {
+    if constexpr (S) { v0 *= s; v1 *= s; }
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(v0), "v"(v1));
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(lo) : "v"(hi), "v"(v0), "v"(v1));
+}
+template <int BIAS>
+__device__ __forceinline__ void wgrad_f16s_body(const WgradArgs& a, const unsigned* absmax_bits, f32x4 (*bshare)[64]) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = lane & 31, kh = lane >> 5;
+    const unsigned nwg = gridDim.x * gridDim.y, v = blockIdx.y * gridDim.x + blockIdx.x;     // XCD-aware (product, slice): see wgrad_big_kernel
+    const unsigned xcd = v & 7, slot = v >> 3;
+    const unsigned full = nwg >> 3, rem = nwg & 7;
+    const unsigned flat = xcd * full + (xcd < rem ? xcd : rem) + slot;
+    const int b = (int)(flat / gridDim.x);
+    const unsigned slice = flat - (unsigned)b * gridDim.x;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = wm * 128, n0 = wn * 128;
+    const bool aok = m0 + 4 * i < a.M[b], bok = n0 + 4 * i < a.N[b];
+    const float* abase = a.dlt[b];
+    const float* bbase = a.x[b];
+    const long long ldd = a.ldd[b], ldx = a.ldx[b];
+    // scale of the gradient operand: max|d_raw| in [2^e, 2^(e+1)) -> s = 2^(7 - e), its largest entries land in [2^7, 2^8)
+    const unsigned mb = __builtin_amdgcn_readfirstlane((int)*absmax_bits);
+    int e = (int)((mb >> 23) & 255u) - 127;
+    if (mb == 0u || e < -100) e = -100;                                 // all-zero (or denormal) gradients: any scale does
+    if (e > 100) e = 100;
+    const float sc = __uint_as_float((unsigned)(127 + 7 - e) << 23), inv_sc = __uint_as_float((unsigned)(127 - 7 + e) << 23);
+
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.0f;
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+
+    constexpr int GROUP = 32;                                           // rows per group = two k-steps = four load units of 8 rows
+    const long long slices = gridDim.x;
+    // unit q (0..3) of a group: k-step q >> 1, half h = q & 1; this lane's rows 16 (q >> 1) + 4 h + 8 kh + {0..3}.  One descriptor per unit
+    // (base = the unit's first row, num_records = the bytes of its 12 rows that exist, rebuilt on the SALU), the whole per-lane offset in
+    // the vector operand: rows at or past P and lanes without columns (offset 2^31) read as zeros by the range check, as in wgrad_big_kernel
+    unsigned voa[4], vob[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        voa[r] = aok ? (unsigned)(((8 * kh + r) * ldd + m0 + 4 * i) * 4) : 0x80000000u;
+        vob[r] = bok ? (unsigned)(((8 * kh + r) * ldx + n0 + 4 * i) * 4) : 0x80000000u;
+    }
+    long long req_group = slice;
+    struct Unit { f32x4 A[4], B[4]; };
+    auto request = [&](int q, Unit& u) __attribute__((always_inline)) {
+        const long long row0 = req_group * GROUP + 16 * (q >> 1) + 4 * (q & 1);
+        const __amdgpu_buffer_rsrc_t ra = wg_rsrc(abase, row0, ldd, a.P, 12), rb = wg_rsrc(bbase, row0, ldx, a.P, 12);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            u.A[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, voa[r], 0, 0));
+            u.B[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, vob[r], 0, 0));
+        }
+    };
+    auto open_group = [&]() __attribute__((always_inline)) { req_group += slices; };
+    // operands of the running k-step: [tile column t][dword]: dwords 0, 1 from the k-step's first unit, 2, 3 from its second
+    unsigned ahi[4][4], alo[4][4], bhi[4][4], blo[4][4];
+    auto convert = [&](int h, const Unit& u) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                split_pair<true>(u.A[2 * pr][t], u.A[2 * pr + 1][t], sc, ahi[t][2 * h + pr], alo[t][2 * h + pr]);
+                split_pair<false>(u.B[2 * pr][t], u.B[2 * pr + 1][t], 1.0f, bhi[t][2 * h + pr], blo[t][2 * h + pr]);
+            }
+        if constexpr (BIAS) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bsum += u.A[r];
+        }
+    };
+    auto mfmas = [&]() __attribute__((always_inline)) {
+        f16x8 AH[4], AL[4], BH[4], BL[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            u32x4 w;
+            w[0] = ahi[t][0]; w[1] = ahi[t][1]; w[2] = ahi[t][2]; w[3] = ahi[t][3]; AH[t] = __builtin_bit_cast(f16x8, w);
+            w[0] = alo[t][0]; w[1] = alo[t][1]; w[2] = alo[t][2]; w[3] = alo[t][3]; AL[t] = __builtin_bit_cast(f16x8, w);
+            w[0] = bhi[t][0]; w[1] = bhi[t][1]; w[2] = bhi[t][2]; w[3] = bhi[t][3]; BH[t] = __builtin_bit_cast(f16x8, w);
+            w[0] = blo[t][0]; w[1] = blo[t][1]; w[2] = blo[t][2]; w[3] = blo[t][3]; BL[t] = __builtin_bit_cast(f16x8, w);
+        }
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn) {
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH[tm], BH[tn], acc[tm][tn], 0, 0, 0);
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH[tm], BL[tn], acc[tm][tn], 0, 0, 0);
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AL[tm], BH[tn], acc[tm][tn], 0, 0, 0);
+            }
+    };
+    Unit u0, u1, u2, u3;
+    request(0, u0); request(1, u1); request(2, u2); request(3, u3);
+    const long long all_groups = (a.P + GROUP - 1) / GROUP;
+    const long long n_groups = (all_groups + slices - 1) / slices;       // per workgroup; surplus groups multiply zeros
+    for (long long g = 0; g < n_groups; ++g) {
+        open_group();                                                    // the NEXT group's rows: every unit is requested a whole group ahead
+        convert(0, u0); request(0, u0);
+        convert(1, u1); request(1, u1);
+        mfmas();
+        convert(0, u2); request(2, u2);
+        convert(1, u3); request(3, u3);
+        mfmas();
+    }
+    const int lane_o = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int i_o = lane_o & 31, kh_o = lane_o >> 5;
+    float* out = a.partial + ((size_t)b * a.slices + slice) * (256 * 256);
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + 4 * ((r & 3) + 8 * (r >> 2) + 4 * kh_o) + tm;
+            f32x4 vv;
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn) { float t; asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(t) : "a"(acc[tm][tn][r])); vv[tn] = t * inv_sc; }
+            *(f32x4*)(out + (size_t)m * 256 + n0 + 4 * i_o) = vv;
+        }
+    if (a.want_bias[b] != 0) {                                           // uniform over the workgroup; the wn == 0 waves summed every row
+        if constexpr (BIAS) {
+            f32x4 sv;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) sv[c] = bsum[c] + __shfl_xor(bsum[c], 32, 64);
+            if (kh_o == 0) *(f32x4*)(a.bpartial + ((size_t)b * a.slices + slice) * 256 + m0 + 4 * i_o) = sv;
+        }
+    }
+    (void)bshare;
+}
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void wgrad_f16s_kernel(const WgradArgs a, const unsigned* absmax_bits) {
+    // FP16_OVFL (MODE bit 23): f16 conversions that overflow saturate at the f16 maximum instead of returning inf
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1");
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if ((wave & 1) == 0) wgrad_f16s_body<1>(a, absmax_bits, nullptr);    // the two waves of a row pair hold the same gradient columns: one sums them
+    else wgrad_f16s_body<0>(a, absmax_bits, nullptr);
+}
+
 // Products with one NARROW operand: the encoded inputs gamma(x) (63 columns) and gamma(d) (27), row pitch 90, and the
 // 3-wide colour / 1-wide density gradients in d_raw (row pitch 4).  The other operand is a W- or W/2-wide row-major tensor.
 // One WAVE owns all of the output, wide (128 WQ columns, fetched like wgrad_big_kernel: lane i takes columns 4i..4i+3 of
@@ -637,6 +800,7 @@ int train_layout(const mi_nerf_net* net, int64_t n_rays, int S, mi_nerf_train_la
     L->delta_d = off; off += al256(p * (W / 2) * 4) + WGRAD_OVERRUN_PAD;
     L->emb = off;     off += al256(p * in_all * 4);
     L->partial = off; off += al256(WGRAD_PARTIAL_FLOATS * 4);
+    off += 256;                                                  // max|d_raw| of the call (split-precision weight gradients), right behind the partials
     L->work_bytes = off;
     return MI_NERF_OK;
 }
@@ -646,7 +810,8 @@ int train_layout(const mi_nerf_net* net, int64_t n_rays, int S, mi_nerf_train_la
 // slice) shrink by the same factor, and so does the fixed cost that kept a lone 256x256 product at ~75 % of the MFMA peak.
 struct WideProduct { const float* dlt; int ldd, M; const float* x; int ldx, N; float* out; int ldo; float* bias; };
 
-static int run_wgrad_batch(const WideProduct* pr, int n, long long P, float* partial, hipStream_t st) {
+// absmax: NULL = fp32 MFMA (wgrad_big_kernel); else the device word holding max|d_raw| and the products run in split precision
+static int run_wgrad_batch(const WideProduct* pr, int n, long long P, float* partial, hipStream_t st, const unsigned* absmax = nullptr) {
     MN_CHECK_ARG(n >= 1 && n <= WG_MAXB, "internal: %d products in a batch", n);
     WgradArgs a{};
     ReduceBatch rb{};
@@ -669,7 +834,8 @@ static int run_wgrad_batch(const WideProduct* pr, int n, long long P, float* par
     a.P = P; a.slices = slices;
     a.partial = partial;
     a.bpartial = partial + (size_t)n * slices * 65536;
-    hipLaunchKernelGGL(wgrad_big_kernel, dim3(slices, n), dim3(256), 0, st, a);
+    if (absmax) hipLaunchKernelGGL(wgrad_f16s_kernel, dim3(slices, n), dim3(256), 0, st, a, absmax);
+    else hipLaunchKernelGGL(wgrad_big_kernel, dim3(slices, n), dim3(256), 0, st, a);
     MN_LAUNCH_CHECK("wgrad_big_kernel");
     hipLaunchKernelGGL(reduce_batch_kernel, dim3((max_total + 63) / 64, n), dim3(256), 0, st, (const float*)partial, (const float*)a.bpartial,
                        slices, rb);
@@ -779,7 +945,7 @@ static int launch_dgrad(const DgradArgs& a, hipStream_t st) {
 // layer inputs gamma(x), gamma(d) are the caller's rows, and (n_rays, S) must be (ceil(n_rows / 32), 32).
 int mlp_backward_fp32(const mi_nerf_net* net, const void* packed_fwd, const void* packed_bwd, const float* rays, const float* z,
                       int64_t n_rays, int S, const float* d_raw, const void* stash, void* work, size_t work_bytes, float* grads,
-                      int stage, hipStream_t st, const float* x_dev, int64_t n_rows) {
+                      int stage, hipStream_t st, const float* x_dev, int64_t n_rows, int mode) {
     MN_CHECK_ARG(net != nullptr, "net is NULL");
     MN_CHECK_ARG(net->L_x >= 0 && net->L_x <= KERNEL_LX && net->L_d >= 0 && net->L_d <= KERNEL_LD, "unsupported encoding L_x=%d L_d=%d", net->L_x, net->L_d);
     MN_CHECK_ARG(net->skip >= -1, "bad skip=%d", net->skip);
@@ -826,13 +992,22 @@ int mlp_backward_fp32(const mi_nerf_net* net, const void* packed_fwd, const void
         embc = emb;
     }
     const size_t PW = (size_t)Ppad * W;
+    // mode bit 0: the wide products in split precision (wgrad_f16s_kernel); their gradient operands are scaled from max|d_raw| of this call
+    unsigned* absmax = nullptr;
+    if (mode & 1) {
+        absmax = (unsigned*)((char*)work + L.partial + al256(WGRAD_PARTIAL_FLOATS * 4));
+        MN_HIP(hipMemsetAsync(absmax, 0, 4, st));
+        const long long nd = (long long)P * 4;
+        hipLaunchKernelGGL(absmax_kernel, dim3(256), dim3(256), 0, st, d_raw, nd, absmax);
+        MN_LAUNCH_CHECK("absmax_kernel");
+    }
     // wide products (both sides W or W/2 wide) in one launch: trunk layers 1..D-1 (activation part), linear_feat, linear_d (feature part)
     const float* h_last = stash_h + (size_t)(D - 1) * PW;
     {
         WideProduct pr[WG_MAXB];
         int n = 0;
         auto flush = [&]() -> int {
-            const int rc = n ? run_wgrad_batch(pr, n, P, partial, st) : MI_NERF_OK;
+            const int rc = n ? run_wgrad_batch(pr, n, P, partial, st, absmax) : MI_NERF_OK;
             n = 0;
             return rc;
         };

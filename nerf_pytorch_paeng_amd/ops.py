@@ -394,8 +394,10 @@ def mlp_rays_train(net: Net, packed: torch.Tensor, rays: torch.Tensor, z: torch.
 
 
 def mlp_backward(net: Net, packed: torch.Tensor, packed_bwd: torch.Tensor, rays: torch.Tensor, z: torch.Tensor, d_raw: torch.Tensor,
-                 stash: torch.Tensor, work: Optional[torch.Tensor] = None, stage: int = 0, grads: Optional[torch.Tensor] = None):
+                 stash: torch.Tensor, work: Optional[torch.Tensor] = None, stage: int = 0, grads: Optional[torch.Tensor] = None,
+                 f16s_wgrad: bool = False):
     """d_raw [n,S,4] -> flat parameter gradient (param_names order).  Returns (grads, work).
+    ``f16s_wgrad``: the W-wide weight-gradient products run in split precision (fp32-grade results, HBM-bound instead of MFMA-bound).
     The weight-gradient kernels write EVERY element of the flat vector (each parameter block is the output of exactly one product's
     reduction), so it is allocated uninitialised; ``grads`` lets a test pass a poisoned buffer to check exactly that."""
     n, S = z.shape
@@ -410,10 +412,10 @@ def mlp_backward(net: Net, packed: torch.Tensor, packed_bwd: torch.Tensor, rays:
     elif grads.numel() != param_count(net):
         raise MiNerfError(f"grads must have {param_count(net)} elements, got {grads.numel()}")
     with _guard(dev):
-        check(lib().mi_nerf_mlp_backward(C.byref(net), dev_ptr(packed, "packed", torch.uint8, 16), dev_ptr(packed_bwd, "packed_bwd", torch.uint8, 16),
-                                         dev_ptr(rays, "rays"), dev_ptr(z, "z"), n, S, dev_ptr(d_raw, "d_raw", align=16),
-                                         dev_ptr(stash, "stash", torch.uint8, 16), dev_ptr(work, "work", torch.uint8, 16), work.numel(),
-                                         dev_ptr(grads, "grads"), int(stage), stream_ptr(dev)), "mi_nerf_mlp_backward")
+        check(lib().mi_nerf_mlp_backward_mode(C.byref(net), dev_ptr(packed, "packed", torch.uint8, 16), dev_ptr(packed_bwd, "packed_bwd", torch.uint8, 16),
+                                              dev_ptr(rays, "rays"), dev_ptr(z, "z"), n, S, dev_ptr(d_raw, "d_raw", align=16),
+                                              dev_ptr(stash, "stash", torch.uint8, 16), dev_ptr(work, "work", torch.uint8, 16), work.numel(),
+                                              dev_ptr(grads, "grads"), int(stage), 1 if f16s_wgrad else 0, stream_ptr(dev)), "mi_nerf_mlp_backward_mode")
     return grads, work
 
 

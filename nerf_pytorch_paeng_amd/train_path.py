@@ -100,7 +100,7 @@ class _RenderTrain(torch.autograd.Function):
         z_c = ops.stratified_z(cfg["near"], cfg["far"], t_rand) if z_override is None else z_override[0]
         raw_c, stash_c = forward_net(flat_c, blob_c, z_c)
         rgb_c, disp_c, _, w_c, _ = ops.composite(raw_c, z_c, rays, want_all=True)
-        ctx.st, ctx.Nf = st, Nf
+        ctx.st, ctx.Nf, ctx.f16s = st, Nf, f16s
         saved = [rays, flat_c, blob_c, z_c, raw_c, stash_c]
         if Nf > 0:
             flat_f = _flat(params[n_each:])
@@ -129,7 +129,7 @@ class _RenderTrain(torch.autograd.Function):
                 return [None] * len(st.names)
             blob_b = ops.pack_apply(st.map_bwd, flat)
             d_raw = ops.composite_backward(raw, z, rays, g_rgb.contiguous().float())
-            grads, _ = ops.mlp_backward(net, blob, blob_b, rays, z, d_raw, stash)
+            grads, _ = ops.mlp_backward(net, blob, blob_b, rays, z, d_raw, stash, f16s_wgrad=ctx.f16s and net.W == 256)
             out, off = [], 0
             for k in st.names:
                 shape = _param_shape(net, k)
