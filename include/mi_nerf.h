@@ -160,6 +160,14 @@ size_t mi_nerf_pack_map_f16s_len(const mi_nerf_net* net);
 int mi_nerf_pack_map_f16s(const mi_nerf_net* net, int32_t* map_host, size_t map_len);
 int mi_nerf_pack_apply_f16s(const mi_nerf_net* net, const int32_t* map_dev, const float* flat_dev, void* blob_dev, size_t blob_bytes,
                             uint32_t* out_of_range_dev, void* stream);
+/* the TRANSPOSED weights for the split-precision backward-data chain (mi_nerf_mlp_backward_mode, mode bit 1): host packer, and the
+ * device-side re-pack through a gather map like the forward blob's */
+size_t mi_nerf_packed_bytes_bwd_f16s(const mi_nerf_net* net);
+int mi_nerf_pack_weights_bwd_f16s(const mi_nerf_net* net, const mi_nerf_params* params, void* host_blob, size_t blob_bytes);
+size_t mi_nerf_pack_map_bwd_f16s_len(const mi_nerf_net* net);
+int mi_nerf_pack_map_bwd_f16s(const mi_nerf_net* net, int32_t* map_host, size_t map_len);
+int mi_nerf_pack_apply_bwd_f16s(const mi_nerf_net* net, const int32_t* map_dev, const float* flat_dev, void* blob_dev, size_t blob_bytes,
+                                uint32_t* out_of_range_dev, void* stream);
 
 /* a10 post_process(outputs, z_vals, rays_d)                              nerf_process.py:89-140
  * raw [n,S,4], z [n,S], rays [n, ray_stride] with the direction at floats 3..5 when ray_stride == 6, or a
@@ -246,7 +254,9 @@ int mi_nerf_mlp_rays_train(const mi_nerf_net* net, const void* packed_dev, const
 int mi_nerf_mlp_backward(const mi_nerf_net* net, const void* packed_dev, const void* packed_bwd_dev, const float* rays_dev,
                          const float* z_dev, int64_t n_rays, int S, const float* d_raw_dev, const void* stash_dev,
                          void* work_dev, size_t work_bytes, float* grads_dev, int stage, void* stream);
-/* ... with a mode: bit 0 = the nine W-wide weight-gradient products of a network in SPLIT PRECISION (operands converted on the fly to
+/* ... with a mode (bits may be combined; 0 is mi_nerf_mlp_backward): bit 1 = the backward-data chain in SPLIT PRECISION
+ * (dgrad_f16s_kernel: packed_bwd_dev is then the blob of mi_nerf_pack_weights_bwd_f16s / mi_nerf_pack_apply_bwd_f16s, W = 256);
+ * bit 0 = the nine W-wide weight-gradient products of a network in SPLIT PRECISION (operands converted on the fly to
  * f16 hi + lo pairs, three f16 MFMAs per product into one fp32 accumulator, the gradient operand scaled by a power of two taken from
  * max|d_raw| on the device): fp32-grade gradients, the products bound by their HBM reads instead of the fp32 matrix rate.  mode 0 is
  * mi_nerf_mlp_backward. */

@@ -95,6 +95,11 @@ SIGNATURES = {
     "mi_nerf_pack_map_f16s_len": (_SZ, [_NETP]),
     "mi_nerf_pack_map_f16s": (_I, [_NETP, _P, _SZ]),
     "mi_nerf_pack_apply_f16s": (_I, [_NETP, _P, _P, _P, _SZ, _P, _P]),
+    "mi_nerf_packed_bytes_bwd_f16s": (_SZ, [_NETP]),
+    "mi_nerf_pack_weights_bwd_f16s": (_I, [_NETP, C.POINTER(Params), _P, _SZ]),
+    "mi_nerf_pack_map_bwd_f16s_len": (_SZ, [_NETP]),
+    "mi_nerf_pack_map_bwd_f16s": (_I, [_NETP, _P, _SZ]),
+    "mi_nerf_pack_apply_bwd_f16s": (_I, [_NETP, _P, _P, _P, _SZ, _P, _P]),
     "mi_nerf_mlp_backward": (_I, [_NETP, _P, _P, _P, _P, _I64, _I, _P, _P, _P, _SZ, _P, _I, _P]),
     "mi_nerf_mlp_backward_mode": (_I, [_NETP, _P, _P, _P, _P, _I64, _I, _P, _P, _P, _SZ, _P, _I, _I, _P]),
     "mi_nerf_mlp_embedded_train": (_I, [_NETP, _P, _P, _I64, _P, _P, _SZ, _P]),

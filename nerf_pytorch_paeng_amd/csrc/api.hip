@@ -60,6 +60,11 @@ int mlp_rays_f16s_stash(const mi_nerf_net*, const void*, const float*, const flo
 size_t pack_map_f16s_len(const mi_nerf_net*);
 int pack_map_f16s(const mi_nerf_net*, int32_t*, size_t);
 int pack_apply_f16s(const mi_nerf_net*, const int32_t*, const float*, void*, size_t, unsigned*, hipStream_t);
+size_t packed_bytes_bwd_f16s(const mi_nerf_net*);
+int pack_bwd_f16s(const mi_nerf_net*, const mi_nerf_params*, void*, size_t);
+size_t pack_map_bwd_f16s_len(const mi_nerf_net*);
+int pack_map_bwd_f16s(const mi_nerf_net*, int32_t*, size_t);
+int pack_apply_bwd_f16s(const mi_nerf_net*, const int32_t*, const float*, void*, size_t, unsigned*, hipStream_t);
 // the MLP launch of a given precision mode (mi_nerf_render_cfg.use_bf16 / mi_nerf_time_mlp_rays): 0 fp32 MFMA; 1..4 bf16 (launch shape);
 // 5 f16 split precision (fp32-grade results on the f16 matrix pipe, mlp_f16s.hip)
 #define MI_NERF_MODE_F16S 5
@@ -318,6 +323,27 @@ int mi_nerf_pack_map_f16s(const mi_nerf_net* net, int32_t* map_host, size_t map_
     MN_CHECK_ARG(net && map_host, "NULL pointer");
     return pack_map_f16s(net, map_host, map_len);
 }
+size_t mi_nerf_packed_bytes_bwd_f16s(const mi_nerf_net* net) {
+    if (!net) return 0;
+    return packed_bytes_bwd_f16s(net);
+}
+int mi_nerf_pack_weights_bwd_f16s(const mi_nerf_net* net, const mi_nerf_params* params, void* host_blob, size_t blob_bytes) {
+    MN_CHECK_ARG(net && params && host_blob, "NULL pointer");
+    return pack_bwd_f16s(net, params, host_blob, blob_bytes);
+}
+size_t mi_nerf_pack_map_bwd_f16s_len(const mi_nerf_net* net) {
+    if (!net) return 0;
+    return pack_map_bwd_f16s_len(net);
+}
+int mi_nerf_pack_map_bwd_f16s(const mi_nerf_net* net, int32_t* map_host, size_t map_len) {
+    MN_CHECK_ARG(net && map_host, "NULL pointer");
+    return pack_map_bwd_f16s(net, map_host, map_len);
+}
+int mi_nerf_pack_apply_bwd_f16s(const mi_nerf_net* net, const int32_t* map_dev, const float* flat_dev, void* blob_dev, size_t blob_bytes,
+                                uint32_t* out_of_range_dev, void* st) {
+    MN_CHECK_ARG(net, "net is NULL");
+    return pack_apply_bwd_f16s(net, map_dev, flat_dev, blob_dev, blob_bytes, out_of_range_dev, (hipStream_t)st);
+}
 int mi_nerf_pack_apply_f16s(const mi_nerf_net* net, const int32_t* map_dev, const float* flat_dev, void* blob_dev, size_t blob_bytes,
                             uint32_t* out_of_range_dev, void* st) {
     MN_CHECK_ARG(net, "net is NULL");
@@ -333,7 +359,7 @@ int mi_nerf_mlp_backward_mode(const mi_nerf_net* net, const void* packed, const 
                               int64_t n_rays, int S, const float* d_raw, const void* stash, void* work, size_t work_bytes, float* grads,
                               int stage, int mode, void* st) {
     if (int rc = check_net_basic(net)) return rc;
-    MN_CHECK_ARG((mode & ~1) == 0, "unknown backward mode %d", mode);
+    MN_CHECK_ARG((mode & ~3) == 0, "unknown backward mode %d", mode);
     return mlp_backward_fp32(net, packed, packed_bwd, rays, z, n_rays, S, d_raw, stash, work, work_bytes, grads, stage, (hipStream_t)st, nullptr, -1, mode);
 }
 int mi_nerf_mlp_embedded_train(const mi_nerf_net* net, const void* packed, const float* x, int64_t n, float* out, void* stash, size_t stash_bytes,

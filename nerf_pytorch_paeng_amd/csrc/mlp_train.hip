@@ -25,6 +25,8 @@
 namespace minerf {
 
 int stage_embed(const float*, const float*, int64_t, int, int, int, float*, hipStream_t);
+int dgrad_f16s(const mi_nerf_net*, const void*, const float*, const float*, const float*, const unsigned*, const unsigned*, float*, float*, float*, int64_t, int,
+               long long, long long, const unsigned*, hipStream_t);
 
 // ---------------------------------------------------------------------------------------------
 // backward data
@@ -982,7 +984,22 @@ int mlp_backward_fp32(const mi_nerf_net* net, const void* packed_fwd, const void
     a.delta_h = delta_h; a.delta_f = delta_f; a.delta_d = delta_d;
     a.S = S; a.tpr = (S + 31) / 32;
     a.P = Ppad; a.n_valid = P; a.n_wtiles = (long long)n_rays * a.tpr; a.D = D;
-    if (int rc = (W == 256 ? launch_dgrad<256>(a, st) : launch_dgrad<128>(a, st))) return rc;
+    // mode bit 0: the wide weight-gradient products, bit 1: the backward-data chain in split precision (packed_bwd is then the blob of
+    // mi_nerf_pack_weights_bwd_f16s); both scale their gradient operands from max|d_raw| of this call, taken on the device
+    unsigned* absmax = nullptr;
+    if (mode & 3) {
+        MN_CHECK_ARG(W == 256 && !x_dev, "the split-precision backward is built for W=256 and the ray entry point");
+        absmax = (unsigned*)((char*)work + L.partial + al256(WGRAD_PARTIAL_FLOATS * 4));
+        MN_HIP(hipMemsetAsync(absmax, 0, 4, st));
+        hipLaunchKernelGGL(absmax_kernel, dim3(256), dim3(256), 0, st, d_raw, (long long)P * 4, absmax);
+        MN_LAUNCH_CHECK("absmax_kernel");
+    }
+    if (mode & 2) {
+        if (int rc = dgrad_f16s(net, packed_bwd, a.side + a.o_color_w, a.side + a.o_dens_w, d_raw, a.mask_h, a.mask_g, delta_h, delta_f, delta_d, n_rays, S,
+                                Ppad, P, absmax, st)) return rc;
+    } else {
+        if (int rc = (W == 256 ? launch_dgrad<256>(a, st) : launch_dgrad<128>(a, st))) return rc;
+    }
     if (stage == 1) return MI_NERF_OK;
 
     // layer inputs gamma(x), gamma(d) as rows (nerf_process.py:69-85), or the caller's own rows
@@ -992,15 +1009,7 @@ int mlp_backward_fp32(const mi_nerf_net* net, const void* packed_fwd, const void
         embc = emb;
     }
     const size_t PW = (size_t)Ppad * W;
-    // mode bit 0: the wide products in split precision (wgrad_f16s_kernel); their gradient operands are scaled from max|d_raw| of this call
-    unsigned* absmax = nullptr;
-    if (mode & 1) {
-        absmax = (unsigned*)((char*)work + L.partial + al256(WGRAD_PARTIAL_FLOATS * 4));
-        MN_HIP(hipMemsetAsync(absmax, 0, 4, st));
-        const long long nd = (long long)P * 4;
-        hipLaunchKernelGGL(absmax_kernel, dim3(256), dim3(256), 0, st, d_raw, nd, absmax);
-        MN_LAUNCH_CHECK("absmax_kernel");
-    }
+    if (!(mode & 1)) absmax = nullptr;                          // the wide products stay on the fp32 matrix pipe
     // wide products (both sides W or W/2 wide) in one launch: trunk layers 1..D-1 (activation part), linear_feat, linear_d (feature part)
     const float* h_last = stash_h + (size_t)(D - 1) * PW;
     {

@@ -59,7 +59,9 @@ def pack_module(sd: Dict[str, "np.ndarray | torch.Tensor"], prefix: str, net: Ne
                  ptr(arr("linear_feat.weight"), (W, W)), ptr(arr("linear_feat.bias"), (W,)),
                  ptr(arr("linear_d.weight"), (W // 2, W + in_d)), ptr(arr("linear_d.bias"), (W // 2,)),
                  ptr(arr("linear_color.weight"), (3, W // 2)), ptr(arr("linear_color.bias"), (3,)))
-    if backward:
+    if backward and f16s:
+        size_fn, pack_fn = lib().mi_nerf_packed_bytes_bwd_f16s, lib().mi_nerf_pack_weights_bwd_f16s
+    elif backward:
         size_fn, pack_fn = lib().mi_nerf_packed_bytes_bwd, lib().mi_nerf_pack_weights_bwd
     elif f16s:
         size_fn, pack_fn = lib().mi_nerf_packed_bytes_f16s, lib().mi_nerf_pack_weights_f16s
@@ -349,28 +351,30 @@ def pack_apply_bf16(net: Net, map_dev: torch.Tensor, flat: torch.Tensor) -> torc
     return out
 
 
-def pack_map_f16s(net: Net) -> torch.Tensor:
+def pack_map_f16s(net: Net, backward: bool = False) -> torch.Tensor:
     """Gather map (CPU int32) from the flat parameter vector to the split-precision blob: stream elements (the source weight at its hi and
-    at its lo position), then side-table floats."""
-    n = lib().mi_nerf_pack_map_f16s_len(C.byref(net))
+    at its lo position), then side-table floats (``backward``: the transposed stream, no side tables)."""
+    n = (lib().mi_nerf_pack_map_bwd_f16s_len if backward else lib().mi_nerf_pack_map_f16s_len)(C.byref(net))
     if n == 0:
         check(1, "mi_nerf_pack_map_f16s_len")
     m = torch.empty(n, dtype=torch.int32)
-    check(lib().mi_nerf_pack_map_f16s(C.byref(net), m.data_ptr(), m.numel()), "mi_nerf_pack_map_f16s")
+    check((lib().mi_nerf_pack_map_bwd_f16s if backward else lib().mi_nerf_pack_map_f16s)(C.byref(net), m.data_ptr(), m.numel()), "mi_nerf_pack_map_f16s")
     return m
 
 
-def pack_apply_f16s(net: Net, map_dev: torch.Tensor, flat: torch.Tensor, out_of_range: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Device-side pack of the split-precision blob (uint8) from the flat parameter vector.  ``out_of_range`` (uint32 [1] on the device, or
-    None) counts stream elements whose weight is NaN or beyond the f16 range -- the host packer refuses those."""
+def pack_apply_f16s(net: Net, map_dev: torch.Tensor, flat: torch.Tensor, out_of_range: Optional[torch.Tensor] = None, backward: bool = False) -> torch.Tensor:
+    """Device-side pack of the split-precision blob (uint8) from the flat parameter vector (``backward``: the transposed stream of the
+    split-precision backward-data kernel, map from pack_map_f16s(net, backward=True)).  ``out_of_range`` (int32 [1] on the device, or None)
+    counts stream elements whose weight is NaN or beyond the f16 range -- the host packer refuses those."""
     dev = flat.device
-    nbytes = lib().mi_nerf_packed_bytes_f16s(C.byref(net))
+    nbytes = (lib().mi_nerf_packed_bytes_bwd_f16s if backward else lib().mi_nerf_packed_bytes_f16s)(C.byref(net))
     if nbytes == 0:
         check(1, "mi_nerf_packed_bytes_f16s")
     out = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    fn = lib().mi_nerf_pack_apply_bwd_f16s if backward else lib().mi_nerf_pack_apply_f16s
     with _guard(dev):
-        check(lib().mi_nerf_pack_apply_f16s(C.byref(net), dev_ptr(map_dev, "map", torch.int32), dev_ptr(flat, "flat"), dev_ptr(out, "blob", torch.uint8, 16),
-                                            nbytes, None if out_of_range is None else dev_ptr(out_of_range, "out_of_range", torch.int32), stream_ptr(dev)),
+        check(fn(C.byref(net), dev_ptr(map_dev, "map", torch.int32), dev_ptr(flat, "flat"), dev_ptr(out, "blob", torch.uint8, 16),
+                 nbytes, None if out_of_range is None else dev_ptr(out_of_range, "out_of_range", torch.int32), stream_ptr(dev)),
               "mi_nerf_pack_apply_f16s")
     return out
 
@@ -395,9 +399,10 @@ def mlp_rays_train(net: Net, packed: torch.Tensor, rays: torch.Tensor, z: torch.
 
 def mlp_backward(net: Net, packed: torch.Tensor, packed_bwd: torch.Tensor, rays: torch.Tensor, z: torch.Tensor, d_raw: torch.Tensor,
                  stash: torch.Tensor, work: Optional[torch.Tensor] = None, stage: int = 0, grads: Optional[torch.Tensor] = None,
-                 f16s_wgrad: bool = False):
+                 f16s_wgrad: bool = False, f16s_dgrad: bool = False):
     """d_raw [n,S,4] -> flat parameter gradient (param_names order).  Returns (grads, work).
     ``f16s_wgrad``: the W-wide weight-gradient products run in split precision (fp32-grade results, HBM-bound instead of MFMA-bound).
+    ``f16s_dgrad``: the backward-data chain runs in split precision; ``packed_bwd`` is then the blob of pack_apply_f16s(..., backward=True).
     The weight-gradient kernels write EVERY element of the flat vector (each parameter block is the output of exactly one product's
     reduction), so it is allocated uninitialised; ``grads`` lets a test pass a poisoned buffer to check exactly that."""
     n, S = z.shape
@@ -415,7 +420,7 @@ def mlp_backward(net: Net, packed: torch.Tensor, packed_bwd: torch.Tensor, rays:
         check(lib().mi_nerf_mlp_backward_mode(C.byref(net), dev_ptr(packed, "packed", torch.uint8, 16), dev_ptr(packed_bwd, "packed_bwd", torch.uint8, 16),
                                               dev_ptr(rays, "rays"), dev_ptr(z, "z"), n, S, dev_ptr(d_raw, "d_raw", align=16),
                                               dev_ptr(stash, "stash", torch.uint8, 16), dev_ptr(work, "work", torch.uint8, 16), work.numel(),
-                                              dev_ptr(grads, "grads"), int(stage), 1 if f16s_wgrad else 0, stream_ptr(dev)), "mi_nerf_mlp_backward_mode")
+                                              dev_ptr(grads, "grads"), int(stage), (1 if f16s_wgrad else 0) | (2 if f16s_dgrad else 0), stream_ptr(dev)), "mi_nerf_mlp_backward_mode")
     return grads, work
 
 

@@ -44,8 +44,13 @@ class _TrainState:
         """Gather map of the split-precision blob, built on first use (f16s=True training forward)."""
         if self._map_f16s is None:
             self._map_f16s = ops.pack_map_f16s(self.net).to(self.device)
+            self._map_bwd_f16s = ops.pack_map_f16s(self.net, backward=True).to(self.device)
             self.f16s_out_of_range = torch.zeros(1, dtype=torch.int32, device=self.device)
         return self._map_f16s
+
+    def map_bwd_f16s(self) -> torch.Tensor:
+        self.map_f16s()
+        return self._map_bwd_f16s
 
     def params(self, module: torch.nn.Module) -> List[torch.Tensor]:
         named = dict(module.named_parameters())
@@ -127,9 +132,10 @@ class _RenderTrain(torch.autograd.Function):
         def one(flat, blob, z, raw, stash, g_rgb) -> List[Optional[torch.Tensor]]:
             if g_rgb is None:
                 return [None] * len(st.names)
-            blob_b = ops.pack_apply(st.map_bwd, flat)
+            f16s = ctx.f16s and net.W == 256
+            blob_b = ops.pack_apply_f16s(net, st.map_bwd_f16s(), flat, st.f16s_out_of_range, backward=True) if f16s else ops.pack_apply(st.map_bwd, flat)
             d_raw = ops.composite_backward(raw, z, rays, g_rgb.contiguous().float())
-            grads, _ = ops.mlp_backward(net, blob, blob_b, rays, z, d_raw, stash, f16s_wgrad=ctx.f16s and net.W == 256)
+            grads, _ = ops.mlp_backward(net, blob, blob_b, rays, z, d_raw, stash, f16s_wgrad=f16s, f16s_dgrad=f16s)
             out, off = [], 0
             for k in st.names:
                 shape = _param_shape(net, k)

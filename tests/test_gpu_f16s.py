@@ -268,3 +268,47 @@ def test_f16s_training_step_gradients_match_the_fp32_path(lego_rays):
     model = NeRF(8, 256, 63, 27).to(DEV)
     with pytest.raises(MiNerfError):
         NP.render_rays(rays, model, None, opts, bf16=True)
+
+
+@pytest.mark.parametrize("D,skip", [(8, 4), (3, 0), (2, -1)])
+def test_f16s_backward_stream_device_pack_is_the_host_pack(D, skip):
+    sd = synthetic.make_state_dict(6, D, 256, skips=() if skip < 0 else (skip,))
+    net = weights.infer_net(sd)
+    host = ops.pack_module(sd, "model_fine.", net, backward=True, f16s=True)
+    m = ops.pack_map_f16s(net, backward=True).to(DEV)
+    bad = torch.zeros(1, dtype=torch.int32, device=DEV)
+    dev = ops.pack_apply_f16s(net, m, _flat_params(sd, "model_fine.", net), bad, backward=True)
+    assert torch.equal(dev.cpu(), host) and int(bad) == 0
+
+
+@pytest.mark.parametrize("D,skip,n,S", [(8, 4, 200, 64), (8, 4, 64, 192), (3, 0, 77, 65), (2, -1, 40, 33)])
+def test_f16s_backward_data_chain_matches_the_fp32_kernel(D, skip, n, S, lego_rays):
+    """dgrad_f16s_kernel against mlp_dgrad_kernel on the same stash and the same (tiny) d_raw: every pre-activation gradient row --
+    delta_d, delta_f, delta_h[l] -- within 2e-5 of the tensor's largest entry (two fp32-grade evaluations of the same chain)."""
+    sd = synthetic.make_state_dict(8, D, 256, skips=() if skip < 0 else (skip,))
+    net = weights.infer_net(sd)
+    rays = lego_rays[:n].contiguous()
+    g = torch.Generator(device=DEV).manual_seed(n)
+    z = torch.sort(torch.rand(n, S, device=DEV, generator=g) * 4 + 2, -1)[0]
+    blob = ops.pack_module(sd, "model_fine.", net).to(DEV)
+    _, stash = ops.mlp_rays_train(net, blob, rays, z)
+    d_raw = (3e-5 * torch.randn(n, S, 4, device=DEV, generator=g)).contiguous()
+    d_raw[:, :, 3] *= 0.05                                                       # density gradients are smaller than colour gradients
+    b32 = ops.pack_module(sd, "model_fine.", net, backward=True).to(DEV)
+    b16 = ops.pack_module(sd, "model_fine.", net, backward=True, f16s=True).to(DEV)
+    lay = ops.train_layout(net, n, S)
+    w32 = torch.zeros(lay.work_bytes, dtype=torch.uint8, device=DEV)
+    w16 = torch.full((lay.work_bytes,), 0xCD, dtype=torch.uint8, device=DEV)     # poison: every row must be written
+    ops.mlp_backward(net, blob, b32, rays, z, d_raw, stash, work=w32, stage=1)
+    ops.mlp_backward(net, blob, b16, rays, z, d_raw, stash, work=w16, stage=1, f16s_dgrad=True)
+    torch.cuda.synchronize()
+    P, W = n * S, 256
+    for name, off, cnt in (("delta_d", lay.delta_d, P * W // 2), ("delta_f", lay.delta_f, P * W), ("delta_h", lay.delta_h, D * P * W)):
+        a, b = w32[off:off + 4 * cnt].view(torch.float32), w16[off:off + 4 * cnt].view(torch.float32)
+        assert torch.isfinite(b).all(), name
+        if name == "delta_h":
+            for l in range(D):
+                al, bl = a[l * P * W:(l + 1) * P * W], b[l * P * W:(l + 1) * P * W]
+                assert float((al - bl).abs().max()) <= 2e-5 * float(al.abs().max()), (name, l, float((al - bl).abs().max()), float(al.abs().max()))
+        else:
+            assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()), (name, float((a - b).abs().max()), float(a.abs().max()))
