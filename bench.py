@@ -490,8 +490,9 @@ def worker(args) -> None:
                  "peak_mem_GiB": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
                  "what": "batchify_rays_and_render_by_chunk (grad) + MSE(rgb_c)+MSE(rgb_f) + loss.backward() + Adam.step(), "
                          f"{N_RAYS} rays per GPU, each rank an independent replica (the reference has no data-parallel training)"}
-        # the same step with the two FORWARD launches in split precision (fp32-grade outputs and activation stash; the backward kernels are the
-        # fp32 ones): an extra leg, like f16_split for inference -- ms_per_step / frac above stay the all-fp32-MFMA step's
+        # the same step with its three MFMA kernels in split precision (forward with stash, backward-data chain, the wide weight-gradient
+        # products: f16 hi + lo operands, fp32 accumulate, fp32-grade gradients): an extra leg, like f16_split for inference -- ms_per_step /
+        # frac above stay the all-fp32-MFMA step's
         if not args.no_f16s_leg:
             for _ in range(2):
                 train_step(True)
@@ -504,10 +505,13 @@ def worker(args) -> None:
             barrier()
             ts_ms = 1e3 * max_over_ranks(time.perf_counter() - t0) / train_steps
             assert torch.isfinite(loss).all()
-            train["f16_split_forward"] = {"ms_per_step": round(ts_ms, 3), "rays_per_s": round(world * N_RAYS / (ts_ms * 1e-3), 1),
-                                          "speedup_vs_f32_step": round(t_ms / ts_ms, 3),
-                                          "what": "forward launches by mlp_f16s_kernel<STASH> (f16 hi + lo operands, fp32 accumulate), backward unchanged; "
-                                                  "gradients within the fp32 path's bars of an fp64 evaluation (tests/test_gpu_train.py F11, f16s case)"}
+            train["f16_split"] = {"ms_per_step": round(ts_ms, 3), "rays_per_s": round(world * N_RAYS / (ts_ms * 1e-3), 1),
+                                  "speedup_vs_f32_step": round(t_ms / ts_ms, 3),
+                                  "x_f32_mfma_roofline": round(N_RAYS / (ts_ms * 1e-3) * train_flop_per_ray / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                                  "dtype": "f16 hi+lo split operands, f32 accumulate",
+                                  "what": "batchify_rays_and_render_by_chunk(..., f16s=True): mlp_f16s_kernel<STASH>, dgrad_f16s_kernel, wgrad_f16s_kernel in place of "
+                                          "the three fp32-MFMA kernels (same stash, deltas and gradient layout; narrow products, compositing and Adam unchanged); "
+                                          "gradients within the fp32 path's bars of an fp64 evaluation (tests/test_gpu_train.py F11, f16s case)"}
         # roofline leg of the training kernels' GEMM: the 256x256 weight-gradient products over the fine net's 786 432 points, as the
         # backward pass runs them (nine in one launch: mi_nerf_wgrad_products), and one product launched on its own
         n_pts = N_RAYS * (SC + NF)
