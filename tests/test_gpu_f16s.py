@@ -312,3 +312,57 @@ def test_f16s_backward_data_chain_matches_the_fp32_kernel(D, skip, n, S, lego_ra
                 assert float((al - bl).abs().max()) <= 2e-5 * float(al.abs().max()), (name, l, float((al - bl).abs().max()), float(al.abs().max()))
         else:
             assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()), (name, float((a - b).abs().max()), float(a.abs().max()))
+
+
+def test_f16s_training_loop_follows_the_fp32_loop(lego_rays):
+    """Eight Adam steps through batchify_rays_and_render_by_chunk with f16s=True (all three MFMA kernels of the step in split precision) beside
+    the same eight steps in fp32: the loss goes down and the two trajectories stay together."""
+    from nerf_pytorch_paeng_amd.model import NeRF, get_positional_encoder
+    sd = synthetic.make_state_dict(21, 8, 256)
+    K, H, W = synthetic.lego_camera()
+    n = 512
+    o, d = lego_rays[:n, :3].contiguous(), lego_rays[:n, 3:].contiguous()
+    target = torch.rand(n, 3, device=DEV, generator=torch.Generator(device=DEV).manual_seed(2)) * 0.5 + 0.25
+    opts = make_opts(perturb=1.0, chunk_rays=n)
+    posenc = get_positional_encoder(10), get_positional_encoder(4)
+    hist = {}
+    for mode in (False, True):
+        model = NeRF(8, 256, 63, 27).to(DEV)
+        model.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+        opt = torch.optim.Adam(model.parameters(), lr=5e-4)
+        losses = []
+        for step in range(8):
+            rgb_c, _, rgb_f, _ = NP.batchify_rays_and_render_by_chunk(o, d, model, posenc, H, W, K, opts, seed=100 + step, f16s=mode)
+            opt.zero_grad()
+            loss = ((rgb_c - target) ** 2).mean() + ((rgb_f - target) ** 2).mean()
+            loss.backward()
+            opt.step()
+            losses.append(float(loss))
+        hist[mode] = losses
+        assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    assert max(abs(a - b) for a, b in zip(hist[False], hist[True])) < 2e-3 * max(hist[False]), (hist[False], hist[True])
+
+
+@pytest.mark.parametrize("gain,exact", [(16.0, True), (3000.0, False)])
+def test_f16s_backward_gradient_range(gain, exact, lego_rays):
+    """The split-precision backward scales its gradient operands from max|d_raw| with seven binades of room for what the transposed weights
+    add.  A layer that amplifies the gradient 16x stays inside (results of fp32 grade); one that amplifies it 3000x leaves the f16 range:
+    FP16_OVFL saturates the conversion -- the gradients are then wrong in the saturated entries but never inf / NaN."""
+    D, n, S = 4, 128, 64
+    sd = synthetic.make_state_dict(9, D, 256, skips=())
+    sd["model_fine.linear_feat.weight"] = (sd["model_fine.linear_feat.weight"] * gain).astype(np.float32)
+    sd["model_fine.linear_d.weight"] = (sd["model_fine.linear_d.weight"] / gain).astype(np.float32)       # keep the forward in range
+    net = weights.infer_net(sd)
+    rays = lego_rays[:n].contiguous()
+    g = torch.Generator(device=DEV).manual_seed(4)
+    z = torch.sort(torch.rand(n, S, device=DEV, generator=g) * 4 + 2, -1)[0]
+    blob = ops.pack_module(sd, "model_fine.", net).to(DEV)
+    _, stash = ops.mlp_rays_train(net, blob, rays, z)
+    d_raw = (1e-4 * torch.randn(n, S, 4, device=DEV, generator=g)).contiguous()
+    b32 = ops.pack_module(sd, "model_fine.", net, backward=True).to(DEV)
+    b16 = ops.pack_module(sd, "model_fine.", net, backward=True, f16s=True).to(DEV)
+    g32, _ = ops.mlp_backward(net, blob, b32, rays, z, d_raw, stash)
+    g16, _ = ops.mlp_backward(net, blob, b16, rays, z, d_raw, stash, f16s_wgrad=True, f16s_dgrad=True)
+    assert torch.isfinite(g16).all()
+    if exact:
+        assert float((g16 - g32).abs().max()) <= 1e-4 * float(g32.abs().max())
