@@ -482,6 +482,11 @@ __device__ __forceinline__ void wgrad_f16s_body(const WgradArgs& a, const unsign
     const long long all_groups = (a.P + GROUP - 1) / GROUP;
     const long long n_groups = (all_groups + slices - 1) / slices;       // per workgroup; surplus groups multiply zeros
     for (long long g = 0; g < n_groups; ++g) {
+#ifdef MN_WGF_SYNC
+        // A/B (not shipped): the waves of a workgroup fetch each row twice between them; a barrier per group keeps the second fetch in the
+        // L2 (FETCH_SIZE 19.7 GB per fine-net batch for 14.1 GB of operands without it) but costs more than it saves: step 13.09 -> 13.58 ms
+        __builtin_amdgcn_s_barrier();
+#endif
         open_group();                                                    // the NEXT group's rows: every unit is requested a whole group ahead
         convert(0, u0); request(0, u0);
         convert(1, u1); request(1, u1);
