@@ -1166,6 +1166,7 @@ void dgrad_f16s_kernel(const DArgs a) {
         float dsig[NP];
         float* rowp[NP];
         unsigned msh[NP][4];
+        u32x4b mnext[NP];
         u32x4b bdh[NP][KG0], bdl[NP][KG0];
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
@@ -1213,6 +1214,7 @@ void dgrad_f16s_kernel(const DArgs a) {
                     bdh[p][s][i] = hi; bdl[p][s][i] = lo;
                 }
             }
+            mnext[p] = *(const u32x4b*)(a.mask_h + ((size_t)(a.D - 1) * a.n_wtiles + tcur) * 256 + (size_t)((col + 16 * p) + 32 * (q4 & 1)) * 4);   // G1's output
             rowp[p] = a.delta_f + idx * W + 4 * q4;                                // G0's output rows
 #pragma unroll
             for (int k = 0; k < 4; ++k) msh[p][k] = 0u;
@@ -1238,18 +1240,19 @@ void dgrad_f16s_kernel(const DArgs a) {
         // and this GEMM's own tiles are finished; mask words of the two differ, row pointers too
         f32x4 dwv = czero;
         unsigned mprev[NP][4];
+        const size_t tile_words = (size_t)a.n_wtiles * 256;
         float* rprev[NP];
-        auto gemm = [&](auto sin_c, auto varp_c, auto varo_c, const unsigned* mask_out, float* rows_out) __attribute__((always_inline)) {
+        // mask words are fetched a GEMM ahead (mnext: the words of the NEXT output, requested at this GEMM's start; G1's were requested in the
+        // prologue): a GEMM is 12 k cycles, the load a couple of microseconds
+        auto gemm = [&](auto sin_c, auto varp_c, auto varo_c, const unsigned* mask_next, float* rows_out) __attribute__((always_inline)) {
             constexpr int SIN = decltype(sin_c)::value, SOUT = 1 - SIN, VARP = decltype(varp_c)::value, VARO = decltype(varo_c)::value;
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
                 rprev[p] = rowp[p];
                 rowp[p] = rows_out + out_idx[p] * W + 4 * q4;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) mprev[p][k] = msh[p][k];
-                const u32x4b mv = *(const u32x4b*)(mask_out + ((size_t)tcur * 64 + (col + 16 * p) + 32 * (q4 & 1)) * 4);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) msh[p][k] = mv[k] << sh4;
+                for (int k = 0; k < 4; ++k) { mprev[p][k] = msh[p][k]; msh[p][k] = mnext[p][k] << sh4; }
+                if (mask_next) mnext[p] = *(const u32x4b*)(mask_next + ((size_t)tcur * 64 + (col + 16 * p) + 32 * (q4 & 1)) * 4);
             }
             auto bh = [&](auto p_c, auto ks_c) __attribute__((always_inline)) { return IC<frag_reg(SIN, decltype(p_c)::value, decltype(ks_c)::value, 0)>{}; };
             auto bl = [&](auto p_c, auto ks_c) __attribute__((always_inline)) { return IC<frag_reg(SIN, decltype(p_c)::value, decltype(ks_c)::value, 1)>{}; };
@@ -1268,18 +1271,19 @@ void dgrad_f16s_kernel(const DArgs a) {
                 for (int p = 0; p < NP; ++p) { ph[p] = ah[p]; pl[p] = al[p]; }
             });
         };
-        const size_t tile_words = (size_t)a.n_wtiles * 256;
-        // G1: input d feature (set 0, plain), output d trunk out (+ dens_w d sigma, mask of layer D-1) -> set 1
-        gemm(IC<0>{}, IC<0>{}, IC<2>{}, a.mask_h + (size_t)(a.D - 1) * tile_words, a.delta_h + (size_t)(a.D - 1) * a.P * W);
-        // trunk GEMMs l = D-1 .. 1: output = delta_{l-1}
+        auto mask_of = [&](int layer) -> const unsigned* { return layer >= 0 ? a.mask_h + (size_t)layer * tile_words : nullptr; };
+        // G1: input d feature (set 0, plain), output d trunk out (+ dens_w d sigma, mask of layer D-1) -> set 1; the trunk GEMM behind it (l = D-1)
+        // masks with layer D-2's words
+        gemm(IC<0>{}, IC<0>{}, IC<2>{}, mask_of(a.D - 2), a.delta_h + (size_t)(a.D - 1) * a.P * W);
+        // trunk GEMMs l = D-1 .. 1: output = delta_{l-1}, masked by layer l-1's words; the next one's are layer l-2's
         int l = a.D - 1;
-        if (l >= 1) { gemm(IC<1>{}, IC<2>{}, IC<1>{}, a.mask_h + (size_t)(l - 1) * tile_words, a.delta_h + (size_t)(l - 1) * a.P * W); --l; }
+        if (l >= 1) { gemm(IC<1>{}, IC<2>{}, IC<1>{}, mask_of(l - 2), a.delta_h + (size_t)(l - 1) * a.P * W); --l; }
 #pragma unroll 1
         for (; l >= 2; l -= 2) {
-            gemm(IC<0>{}, IC<1>{}, IC<1>{}, a.mask_h + (size_t)(l - 1) * tile_words, a.delta_h + (size_t)(l - 1) * a.P * W);
-            gemm(IC<1>{}, IC<1>{}, IC<1>{}, a.mask_h + (size_t)(l - 2) * tile_words, a.delta_h + (size_t)(l - 2) * a.P * W);
+            gemm(IC<0>{}, IC<1>{}, IC<1>{}, mask_of(l - 2), a.delta_h + (size_t)(l - 1) * a.P * W);
+            gemm(IC<1>{}, IC<1>{}, IC<1>{}, mask_of(l - 3), a.delta_h + (size_t)(l - 2) * a.P * W);
         }
-        if (l == 1) gemm(IC<0>{}, IC<1>{}, IC<1>{}, a.mask_h, a.delta_h);
+        if (l == 1) gemm(IC<0>{}, IC<1>{}, IC<1>{}, mask_of(-1), a.delta_h);
         // ---- the last GEMM's last tile has no job behind it: finish it here (rows only) ---------------------------------------------------
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 #pragma unroll
