@@ -260,3 +260,47 @@ def test_fragment_file_kernels_own_m0_and_the_agpr_file(src, mfma_name, min_mfma
     for l in lines:                                                               # AGPRs appear only as MFMA B operands / accvgpr_write targets
         if re.search(r"\ba\[?\d", l):
             assert l.startswith("v_accvgpr_write_b32 a") or l.startswith(mfma_name + " v["), l
+
+
+@pytest.mark.parametrize("backward", [False, True])
+@pytest.mark.parametrize("D,skip", [(8, 4), (3, 0), (2, -1)])
+def test_f16s_blobs_reconstruct_the_weights_through_their_gather_maps(D, skip, backward):
+    """Split-precision blobs (forward stream + side tables; transposed backward stream): every stream element named by the gather map holds
+    the hi (first 512 halves of a 1024-half pair block) or lo (second 512) half of that weight, hi + lo 2^-11 == w to 2^-21 relative; the
+    maps cover every weight the chain uses; side-table floats are copies."""
+    from nerf_pytorch_paeng_amd import synthetic, weights
+    sd = synthetic.make_state_dict(17, D, 256, skips=() if skip < 0 else (skip,))
+    net = weights.infer_net(sd)
+    blob = ops.pack_module(sd, "model_fine.", net, backward=backward, f16s=True).numpy()
+    m = ops.pack_map_f16s(net, backward=backward).numpy()
+    flat = np.concatenate([np.asarray(sd["model_fine." + k], dtype=np.float32).reshape(-1) for k in ops.param_names(net)])
+    hdr = blob[:64].view(np.uint32)
+    stream_off, stream_bytes = int(hdr[7]), int(hdr[8])
+    n_stream = stream_bytes // 2
+    st = blob[stream_off:stream_off + stream_bytes].view(np.float16).astype(np.float64)
+    assert m.size >= n_stream and n_stream % 1024 == 0
+    mm = m[:n_stream].reshape(-1, 2, 512)
+    assert np.array_equal(mm[:, 0], mm[:, 1])                                  # a pair block: hi and lo halves of the SAME weights
+    v = st.reshape(-1, 2, 512)
+    rec = v[:, 0] + v[:, 1] / 2048.0
+    used = mm[:, 0] > 0
+    want = flat[mm[:, 0][used] - 1].astype(np.float64)
+    assert np.all(np.abs(rec[used] - want) <= 2.0 ** -21 * np.abs(want) + 2.0 ** -35)     # below the f16 normal range (2^-14) the error is absolute
+    assert np.all(rec[~used] == 0.0)
+    if not backward:
+        side_off, side_floats = int(hdr[10]), int(hdr[11])
+        side = blob[side_off:side_off + 4 * side_floats].view(np.float32)
+        ms = m[n_stream:n_stream + side_floats]
+        assert np.array_equal(side[ms > 0], flat[ms[ms > 0] - 1]) and np.all(side[ms == 0] == 0.0)
+    # coverage: the forward blob names every parameter except none; the backward stream every trunk weight that multiplies an activation
+    names = ops.param_names(net)
+    sizes = [int(np.prod(sd["model_fine." + k].shape)) for k in names]
+    offs = np.cumsum([0] + sizes)
+    hit = np.zeros(flat.size, dtype=bool)
+    hit[m[m > 0] - 1] = True
+    for k, o, sz in zip(names, offs[:-1], sizes):
+        frac = hit[o:o + sz].mean()
+        if not backward:
+            assert frac == 1.0, (k, frac)
+        elif k == "linear_feat.weight" or (k.startswith("linear_x.") and k.endswith(".weight") and not k.startswith("linear_x.0.")):
+            assert frac >= 256.0 / (256.0 + 63.0) - 1e-6, (k, frac)            # the skip layer's gamma(x) block has no gradient path
