@@ -366,3 +366,32 @@ def test_f16s_backward_gradient_range(gain, exact, lego_rays):
     assert torch.isfinite(g16).all()
     if exact:
         assert float((g16 - g32).abs().max()) <= 1e-4 * float(g32.abs().max())
+
+
+def test_f16s_training_llff_and_two_slabs(monkeypatch):
+    """The split-precision step through the NDC (llff) entry, with the batch cut into two autograd nodes (slab size lowered): losses and
+    coarse-network gradients equal the fp32 path's to fp32 rounding; harness.train takes the mode as opts.precision."""
+    from nerf_pytorch_paeng_amd import harness, train_path
+    from nerf_pytorch_paeng_amd.model import NeRF, get_positional_encoder
+    monkeypatch.setattr(train_path, "MAX_TRAIN_RAYS", 96)
+    sd = synthetic.make_state_dict(33, 4, 256, skips=(1,))
+    K, H, W = synthetic.fern_camera()
+    pose = torch.as_tensor(synthetic.fern_pose()[:3, :4], dtype=torch.float32)
+    pix = T(synthetic.pixel_batch(H, W, 160, 3)).to(DEV)
+    o, d = ops.make_o_d_pixels(W, H, K, synthetic.fern_pose(), pix)
+    target = torch.rand(160, 3, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5))
+    opts = make_opts(near=0.0, far=1.0, N_samples_c=32, N_samples_f=33, perturb=1.0, data_type="llff", chunk_rays=160)
+    posenc = get_positional_encoder(10), get_positional_encoder(4)
+    res = {}
+    for mode in (False, True):
+        model = NeRF(4, 256, 63, 27, skips=[1]).to(DEV)
+        model.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+        rgb_c, _, rgb_f, _ = NP.batchify_rays_and_render_by_chunk(o, d, model, posenc, H, W, K, opts, seed=9, f16s=mode)
+        lc, lf = ((rgb_c - target) ** 2).mean(), ((rgb_f - target) ** 2).mean()
+        (lc + lf).backward()
+        res[mode] = (float(lc), float(lf), {k: p.grad.clone() for k, p in model.model_coarse.named_parameters()})
+    assert abs(res[True][0] - res[False][0]) < 1e-6 and abs(res[True][1] - res[False][1]) < 2e-5
+    for k, a in res[False][2].items():
+        b = res[True][2][k]
+        assert torch.isfinite(b).all() and float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()) + 1e-12, k
+    assert harness._precision(make_opts(precision="f16s")) == {"bf16": False, "f16s": True}
