@@ -1114,7 +1114,7 @@ void dgrad_f16s_kernel(const DArgs a) {
     asm volatile("" ::: "a255");
     asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1");       // FP16_OVFL: a conversion beyond the f16 range saturates
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* cw = (float*)(smem + RING_BYTES_S);                 // colour head [3][W/2], then the density head [W]
+    float* cw = (float*)(smem + RING_BYTES_S);                 // colour head [3][W/2], then the density head [W], then a mask block per wave
     float* dwl = cw + 3 * (W / 2);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1156,6 +1156,8 @@ void dgrad_f16s_kernel(const DArgs a) {
     const f32x4 czero = {0.f, 0.f, 0.f, 0.f};
     auto csel0 = [&](int) __attribute__((always_inline)) -> const f32x4& { return czero; };
     const int sh4 = 4 * (q4 >> 1);                                  // this lane's nibble of a mask byte pair (see stash_tile)
+    const char* mlds = (const char*)(dwl + W) + wave * (a.D * 1024);
+    const unsigned mlds_m0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + RING_BYTES_S + (3 * (W / 2) + W) * 4 + wave * (a.D * 1024);
 
     for (unsigned it = 0; it < a.n_iter; ++it) {
         const unsigned n_tile = unit_of(it);
@@ -1166,8 +1168,19 @@ void dgrad_f16s_kernel(const DArgs a) {
         float dsig[NP];
         float* rowp[NP];
         unsigned msh[NP][4];
-        u32x4b mnext[NP];
         u32x4b bdh[NP][KG0], bdl[NP][KG0];
+        // ---- this tile's ReLU' words, all layers: [D][64 lanes][16 bytes] straight into the wave's LDS block.  The ring's own DMAs are in mid
+        // slot here (five of the slot's eight issued: the A pipeline runs three pairs ahead), and they set M0 only at their first and fifth:
+        // M0 goes back to what the sixth expects.
+        {
+            const char* mg = (const char*)a.mask_h + ((size_t)tcur * 64 + lane) * 16;
+            const size_t layer_bytes = (size_t)a.n_wtiles * 1024;
+            for (int ml = 0; ml < a.D; ++ml) {
+                set_m0(mlds_m0 + ml * 1024);
+                dma16<0>(mg + ml * layer_bytes);
+            }
+            set_m0(ring.fetch_lds + 4096);
+        }
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             const int sample = (int)chunk * 32 + 16 * p + col;
@@ -1214,7 +1227,6 @@ void dgrad_f16s_kernel(const DArgs a) {
                     bdh[p][s][i] = hi; bdl[p][s][i] = lo;
                 }
             }
-            mnext[p] = *(const u32x4b*)(a.mask_h + ((size_t)(a.D - 1) * a.n_wtiles + tcur) * 256 + (size_t)((col + 16 * p) + 32 * (q4 & 1)) * 4);   // G1's output
             rowp[p] = a.delta_f + idx * W + 4 * q4;                                // G0's output rows
 #pragma unroll
             for (int k = 0; k < 4; ++k) msh[p][k] = 0u;
@@ -1240,19 +1252,19 @@ void dgrad_f16s_kernel(const DArgs a) {
         // and this GEMM's own tiles are finished; mask words of the two differ, row pointers too
         f32x4 dwv = czero;
         unsigned mprev[NP][4];
-        const size_t tile_words = (size_t)a.n_wtiles * 256;
         float* rprev[NP];
-        // mask words are fetched a GEMM ahead (mnext: the words of the NEXT output, requested at this GEMM's start; G1's were requested in the
-        // prologue): a GEMM is 12 k cycles, the load a couple of microseconds
-        auto gemm = [&](auto sin_c, auto varp_c, auto varo_c, const unsigned* mask_next, float* rows_out) __attribute__((always_inline)) {
+        // The ReLU' words of every layer for this tile sit in the wave's LDS block (one 1 KiB LDS-DMA per layer, issued in the prologue: a
+        // per-GEMM global load would be waited for by the very next ring advance -- every advance waits for all older vector memory
+        // operations -- and cost 0.6 ms of the step).  mask_layer: the layer whose words mask this GEMM's OUTPUT.
+        auto gemm = [&](auto sin_c, auto varp_c, auto varo_c, int mask_layer, float* rows_out) __attribute__((always_inline)) {
             constexpr int SIN = decltype(sin_c)::value, SOUT = 1 - SIN, VARP = decltype(varp_c)::value, VARO = decltype(varo_c)::value;
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
                 rprev[p] = rowp[p];
                 rowp[p] = rows_out + out_idx[p] * W + 4 * q4;
+                const u32x4b mv = *(const u32x4b*)(mlds + mask_layer * 1024 + ((col + 16 * p) + 32 * (q4 & 1)) * 16);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { mprev[p][k] = msh[p][k]; msh[p][k] = mnext[p][k] << sh4; }
-                if (mask_next) mnext[p] = *(const u32x4b*)(mask_next + ((size_t)tcur * 64 + (col + 16 * p) + 32 * (q4 & 1)) * 4);
+                for (int k = 0; k < 4; ++k) { mprev[p][k] = msh[p][k]; msh[p][k] = mv[k] << sh4; }
             }
             auto bh = [&](auto p_c, auto ks_c) __attribute__((always_inline)) { return IC<frag_reg(SIN, decltype(p_c)::value, decltype(ks_c)::value, 0)>{}; };
             auto bl = [&](auto p_c, auto ks_c) __attribute__((always_inline)) { return IC<frag_reg(SIN, decltype(p_c)::value, decltype(ks_c)::value, 1)>{}; };
@@ -1271,19 +1283,17 @@ void dgrad_f16s_kernel(const DArgs a) {
                 for (int p = 0; p < NP; ++p) { ph[p] = ah[p]; pl[p] = al[p]; }
             });
         };
-        auto mask_of = [&](int layer) -> const unsigned* { return layer >= 0 ? a.mask_h + (size_t)layer * tile_words : nullptr; };
-        // G1: input d feature (set 0, plain), output d trunk out (+ dens_w d sigma, mask of layer D-1) -> set 1; the trunk GEMM behind it (l = D-1)
-        // masks with layer D-2's words
-        gemm(IC<0>{}, IC<0>{}, IC<2>{}, mask_of(a.D - 2), a.delta_h + (size_t)(a.D - 1) * a.P * W);
-        // trunk GEMMs l = D-1 .. 1: output = delta_{l-1}, masked by layer l-1's words; the next one's are layer l-2's
+        // G1: input d feature (set 0, plain), output d trunk out (+ dens_w d sigma, mask of layer D-1) -> set 1
+        gemm(IC<0>{}, IC<0>{}, IC<2>{}, a.D - 1, a.delta_h + (size_t)(a.D - 1) * a.P * W);
+        // trunk GEMMs l = D-1 .. 1: output = delta_{l-1}, masked by layer l-1's words
         int l = a.D - 1;
-        if (l >= 1) { gemm(IC<1>{}, IC<2>{}, IC<1>{}, mask_of(l - 2), a.delta_h + (size_t)(l - 1) * a.P * W); --l; }
+        if (l >= 1) { gemm(IC<1>{}, IC<2>{}, IC<1>{}, l - 1, a.delta_h + (size_t)(l - 1) * a.P * W); --l; }
 #pragma unroll 1
         for (; l >= 2; l -= 2) {
-            gemm(IC<0>{}, IC<1>{}, IC<1>{}, mask_of(l - 2), a.delta_h + (size_t)(l - 1) * a.P * W);
-            gemm(IC<1>{}, IC<1>{}, IC<1>{}, mask_of(l - 3), a.delta_h + (size_t)(l - 2) * a.P * W);
+            gemm(IC<0>{}, IC<1>{}, IC<1>{}, l - 1, a.delta_h + (size_t)(l - 1) * a.P * W);
+            gemm(IC<1>{}, IC<1>{}, IC<1>{}, l - 2, a.delta_h + (size_t)(l - 2) * a.P * W);
         }
-        if (l == 1) gemm(IC<0>{}, IC<1>{}, IC<1>{}, mask_of(-1), a.delta_h);
+        if (l == 1) gemm(IC<0>{}, IC<1>{}, IC<1>{}, 0, a.delta_h);
         // ---- the last GEMM's last tile has no job behind it: finish it here (rows only) ---------------------------------------------------
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 #pragma unroll
@@ -1367,7 +1377,8 @@ int dgrad_f16s(const mi_nerf_net* net, const void* packed_bwd_f16s_dev, const fl
     MN_CHECK_ARG(n_wtiles < (1LL << 30), "too many points for one launch: %lld rays x %d samples", (long long)n_rays, S);
     a.n_wtiles = (unsigned)n_wtiles;
     a.absmax_bits = absmax_dev;
-    const size_t lds = RING_BYTES_S + (size_t)(3 * 128 + 256) * 4;
+    const size_t lds = RING_BYTES_S + (size_t)(3 * 128 + 256) * 4 + (size_t)4 * net->D * 1024;      // ring | heads | per wave: D layers of mask words
+    MN_CHECK_ARG(lds <= 160 * 1024, "the split-precision backward-data kernel keeps a tile's ReLU' words of all layers in LDS: D = %d does not fit (D <= 15)", net->D);
     static LdsOptIn opt_in = {};
     if (int rc = ensure_lds_opt_in(opt_in, (const void*)dgrad_f16s_kernel)) return rc;
     const int n_cus = device_cus();

@@ -133,9 +133,10 @@ class _RenderTrain(torch.autograd.Function):
             if g_rgb is None:
                 return [None] * len(st.names)
             f16s = ctx.f16s and net.W == 256
-            blob_b = ops.pack_apply_f16s(net, st.map_bwd_f16s(), flat, st.f16s_out_of_range, backward=True) if f16s else ops.pack_apply(st.map_bwd, flat)
+            f16s_dgrad = f16s and net.D <= 15              # the split-precision chain keeps a tile's ReLU' words of all layers in LDS
+            blob_b = ops.pack_apply_f16s(net, st.map_bwd_f16s(), flat, st.f16s_out_of_range, backward=True) if f16s_dgrad else ops.pack_apply(st.map_bwd, flat)
             d_raw = ops.composite_backward(raw, z, rays, g_rgb.contiguous().float())
-            grads, _ = ops.mlp_backward(net, blob, blob_b, rays, z, d_raw, stash, f16s_wgrad=f16s, f16s_dgrad=f16s)
+            grads, _ = ops.mlp_backward(net, blob, blob_b, rays, z, d_raw, stash, f16s_wgrad=f16s, f16s_dgrad=f16s_dgrad)
             out, off = [], 0
             for k in st.names:
                 shape = _param_shape(net, k)
