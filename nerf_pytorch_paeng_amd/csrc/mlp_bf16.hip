@@ -51,6 +51,10 @@
 #include "common.h"
 #include "layout.h"
 
+#ifndef MN_BF16_PF_T
+#define MN_BF16_PF_T 3
+#define MN_BF16_PF_KS 2
+#endif
 namespace minerf {
 
 typedef unsigned u32x4b __attribute__((ext_vector_type(4)));
@@ -835,7 +839,10 @@ __device__ __forceinline__ void run_phase(const MlpArgsB& a, const PhaseB ph, ch
                     if constexpr (t > 0) pack_sched<NP, true, SIN, t - 1, ks, p>(prev, pt);
                     if constexpr (t == 0 && ks == 6)            // the density tile finished >= 24 MFMAs ago: keep its one useful register
                         asm volatile("v_mov_b32 %0, %1" : "=v"(dens[p]) : "v"(hd[p][3]));
-                    if constexpr (t == 2 && ks == 6 && p == 1) load_inputs(it + 1 < ph.n_iter ? it + 1 : it);      // next pair's rays and depths, ~3000 cycles ahead
+                    // next pair's rays and depths, two quads BEHIND a ring advance (tail position 162 = slot 5, quad 2): an advance waits for every
+                    // older vector memory operation, and two quads before one (position 158, where this sat) is the worst place for a load.  A/B: 0.2 %;
+                    // the loads and their index arithmetic cost the kernel 2 % in all (ablation build without them).
+                    if constexpr (t == MN_BF16_PF_T && ks == MN_BF16_PF_KS && p == 1) load_inputs(it + 1 < ph.n_iter ? it + 1 : it);
                     if constexpr (ks == 5) {
                         if constexpr (t + 1 < NT / 2) cnextd[p] = *(const f32x4*)(scratch + (p >> 1) * (W / 2) + MT * (t + 1) + 4 * q4);
                         else if constexpr (p == 1) {                    // colour tile: rows 0..2 = colour bias (lane quarter 0 only)
