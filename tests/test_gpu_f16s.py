@@ -343,12 +343,12 @@ def test_f16s_training_loop_follows_the_fp32_loop(lego_rays):
     assert max(abs(a - b) for a, b in zip(hist[False], hist[True])) < 2e-3 * max(hist[False]), (hist[False], hist[True])
 
 
-@pytest.mark.parametrize("gain,exact", [(16.0, True), (3000.0, False)])
-def test_f16s_backward_gradient_range(gain, exact, lego_rays):
+@pytest.mark.parametrize("gain,exact,n,S", [(16.0, True, 128, 64), (1.0, True, 77, 65), (3000.0, False, 128, 64)])
+def test_f16s_backward_gradient_range(gain, exact, n, S, lego_rays):
     """The split-precision backward scales its gradient operands from max|d_raw| with seven binades of room for what the transposed weights
     add.  A layer that amplifies the gradient 16x stays inside (results of fp32 grade); one that amplifies it 3000x leaves the f16 range:
     FP16_OVFL saturates the conversion -- the gradients are then wrong in the saturated entries but never inf / NaN."""
-    D, n, S = 4, 128, 64
+    D = 4                                                                       # (77 x 65 = 5005 points: not a multiple of the 32-row load group)
     sd = synthetic.make_state_dict(9, D, 256, skips=())
     sd["model_fine.linear_feat.weight"] = (sd["model_fine.linear_feat.weight"] * gain).astype(np.float32)
     sd["model_fine.linear_d.weight"] = (sd["model_fine.linear_d.weight"] / gain).astype(np.float32)       # keep the forward in range
