@@ -18,13 +18,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libmi_nerf.so")
-SOURCES = ["api.hip", "stages.hip", "mlp_fp32.hip", "mlp_bf16.hip", "mlp_f16s.hip", "mlp_train.hip", "frames.hip", "pack.cpp"]
+SOURCES = ["api.hip", "stages.hip", "mlp_fp32.hip", "mlp_bf16.hip", "mlp_f16s.hip", "mlp_f16s_stash.hip", "dgrad_f16s.hip", "mlp_train.hip", "frames.hip", "pack.cpp"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
          # the MLP kernel's register-resident design needs its k-loops FULLY unrolled (static register indices)
          "-mllvm", "-pragma-unroll-threshold=1000000"]
 # mlp_bf16.hip manages the whole AGPR file by hand (explicit a[N] operands in asm statements): hipcc must not park spilled VGPRs there
-FILE_FLAGS = {"mlp_bf16.hip": ["-mllvm", "-amdgpu-spill-vgpr-to-agpr=0"], "mlp_f16s.hip": ["-mllvm", "-amdgpu-spill-vgpr-to-agpr=0"]}
+FILE_FLAGS = {"mlp_bf16.hip": ["-mllvm", "-amdgpu-spill-vgpr-to-agpr=0"], "mlp_f16s.hip": ["-mllvm", "-amdgpu-spill-vgpr-to-agpr=0"],
+              "mlp_f16s_stash.hip": ["-mllvm", "-amdgpu-spill-vgpr-to-agpr=0"], "dgrad_f16s.hip": ["-mllvm", "-amdgpu-spill-vgpr-to-agpr=0"]}
 
 
 def _hipcc() -> str:
@@ -57,7 +58,7 @@ def _compile(src: str, force: bool, extra=(), tag: str = "") -> str:
 
 
 def build_library(force: bool = False, verbose: bool = False) -> str:
-    with ThreadPoolExecutor(max_workers=4) as ex:
+    with ThreadPoolExecutor(max_workers=6) as ex:
         objs = list(ex.map(lambda s: _compile(s, force), SOURCES))
     if force or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
         cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", LIB]

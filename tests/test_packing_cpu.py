@@ -225,9 +225,10 @@ def test_bf16_pack_map_reproduces_the_host_blob(D, skip):
     assert np.array_equal(src[sb // 2:], want_side)
 
 
-@pytest.mark.parametrize("src,mfma_name,min_mfma", [("mlp_bf16.hip", "v_mfma_f32_16x16x32_bf16", 4000), ("mlp_f16s.hip", "v_mfma_f32_16x16x32_f16", 6000)])
+@pytest.mark.parametrize("src,mfma_name,min_mfma", [("mlp_bf16.hip", "v_mfma_f32_16x16x32_bf16", 4000), ("mlp_f16s.hip", "v_mfma_f32_16x16x32_f16", 6000),
+                                                   ("mlp_f16s_stash.hip", "v_mfma_f32_16x16x32_f16", 6000), ("dgrad_f16s.hip", "v_mfma_f32_16x16x32_f16", 3000)])
 def test_fragment_file_kernels_own_m0_and_the_agpr_file(src, mfma_name, min_mfma):
-    """mlp_bf16.hip and mlp_f16s.hip set M0 without saving it and address the whole AGPR file by explicit register numbers: both are only
+    """mlp_bf16.hip and the split-precision kernels (mlp_f16s.hip, mlp_f16s_stash.hip, dgrad_f16s.hip) set M0 without saving it and address the whole AGPR file by explicit register numbers: both are only
     sound while hipcc itself never touches M0 / an AGPR in those kernels.  Disassemble the objects and check."""
     import os
     import re
