@@ -8,6 +8,11 @@
 #include "common.h"
 #include "layout.h"
 
+// where the next unit's inputs are requested in the view-direction layer (job, k-step): behind a ring advance (pair 161 of the tail = slot 10, quad 2)
+#ifndef MN_F16S_PF_T
+#define MN_F16S_PF_T 3
+#define MN_F16S_PF_KS 1
+#endif
 namespace minerf {
 namespace f16s {
 
@@ -616,7 +621,7 @@ void mlp_f16s_kernel(const Args a) {
                         stash_tile<true, true, t - 1>(pt[2 * (sub - 4)], pt[2 * (sub - 4) + 1], rowp[sub - 4], mw[sub - 4], nib_sh);
                     if constexpr (t == 0 && ks == 7 && sub >= 4)            // the density tile finished >= 40 MFMAs ago: keep its one useful value
                         asm volatile("v_fma_f32 %0, %1, %3, %2" : "=v"(dens[sub - 4]) : "v"(hdl[sub - 4][3]), "v"(hdh[sub - 4][3]), "s"(dn));
-                    if constexpr (t == 2 && ks == 7 && sub == 3) load_inputs(it + 1 < a.n_iter ? it + 1 : it);      // next unit's ray and depths
+                    if constexpr (t == MN_F16S_PF_T && ks == MN_F16S_PF_KS && sub == 3) load_inputs(it + 1 < a.n_iter ? it + 1 : it);      // next unit's ray and depths
                     if constexpr (ks == 7 && sub == 2) {
                         if constexpr (t + 1 < NT / 2) { cnextd[0] = *(const f32x4*)(scratch + MT * (t + 1) + 4 * q4); cnextd[1] = cnextd[0]; }
                         else {                                          // colour tile: rows 0..2 = colour bias (lane quarter 0 only)
