@@ -83,19 +83,35 @@ def _oracle_backward(net, sd, prefix, rays, z, d_raw):
     return out.detach(), {k: psd[prefix + k].grad for k in names}, taps
 
 
-@pytest.mark.parametrize("D,W,skip,n,S", [(8, 256, 4, 24, 40), (4, 128, 1, 10, 33), (3, 256, -1, 7, 64)])
-def test_mlp_backward_vs_autograd(D, W, skip, n, S):
+@pytest.mark.parametrize("D,W,skip,n,S,f16s", [(8, 256, 4, 24, 40, False), (4, 128, 1, 10, 33, False), (3, 256, -1, 7, 64, False),
+                                                (8, 256, 4, 24, 40, True), (3, 256, -1, 7, 64, True), (2, 256, 0, 5, 33, True)])
+def test_mlp_backward_vs_autograd(D, W, skip, n, S, f16s):
+    """Stash, per-layer gradients and parameter gradients of one network against autograd on the CPU oracle, stage by stage.
+    ``f16s``: the three MFMA kernels in split precision (mlp_f16s_kernel<STASH>, dgrad_f16s_kernel, wgrad_f16s_kernel) -- same bars."""
     net, sd, rays, z, d_raw = _mlp_case(D, W, skip, n, S, 11 + D)
     prefix = "model_coarse."
-    raw_want, grads_want, taps = _oracle_backward(net, sd, prefix, rays, z, d_raw)
+    _, _, taps0 = _oracle_backward(net, sd, prefix, rays, z, d_raw)               # forward taps (pre-activations) of the oracle
     packed = ops.pack_module(sd, prefix, net).to(DEV)
-    packed_bwd = ops.pack_module(sd, prefix, net, backward=True).to(DEV)
+    packed_fwd = ops.pack_module(sd, prefix, net, f16s=True).to(DEV) if f16s else packed
+    packed_bwd = ops.pack_module(sd, prefix, net, backward=True, f16s=f16s).to(DEV)
+    bw = dict(f16s_wgrad=f16s, f16s_dgrad=f16s)
     raysd, zd, d_rawd = rays.to(DEV), z.to(DEV), d_raw.to(DEV)
     P = n * S
 
     # 1. training forward == inference forward, and the stash holds the post-activation rows
-    raw, stash = ops.mlp_rays_train(net, packed, raysd, zd)
-    assert torch.equal(raw, ops.mlp_rays(net, packed, raysd, zd))
+    raw, stash = ops.mlp_rays_train(net, packed_fwd, raysd, zd, f16s=f16s)
+    assert torch.equal(raw, ops.mlp_rays(net, packed_fwd, raysd, zd, f16s=f16s))
+    # A unit whose pre-activation is within rounding of zero has an ambiguous ReLU derivative: the kernel and the oracle may take different
+    # sides, and one such unit changes its point's contribution to every gradient below it.  Points where the two forwards disagree on a
+    # sign (a few in a thousand for the split-precision forward, rarer for the fp32 one) get a zero output gradient on both sides.
+    v0 = ops.train_views(net, n, S, stash=stash)
+    knife = ((v0["stash_g"].cpu() > 0) != (taps0["ad"].detach() > 0)).any(dim=1)
+    for l in range(D):
+        knife |= ((v0["stash_h"][l].cpu() > 0) != (taps0[f"a{l}"].detach() > 0)).any(dim=1)
+    assert int(knife.sum()) <= max(3, P // 100), int(knife.sum())
+    d_raw = (d_raw.reshape(-1, 4) * (~knife).float()[:, None]).reshape(n, S, 4).contiguous()
+    d_rawd = d_raw.to(DEV)
+    raw_want, grads_want, taps = _oracle_backward(net, sd, prefix, rays, z, d_raw)
     assert rel_err(raw.reshape(-1, 4), raw_want) < 2e-5
     v = ops.train_views(net, n, S, stash=stash)
     for l in range(D):
@@ -104,22 +120,28 @@ def test_mlp_backward_vs_autograd(D, W, skip, n, S):
     assert rel_err(v["stash_g"], torch.relu(taps["ad"]).detach()) < 2e-5
 
     # 2. backward data: per-layer pre-activation gradients.  A ReLU whose pre-activation is within rounding of zero can
-    # flip between the two implementations; such rows are rare and excluded by comparing only where the oracle's
-    # pre-activation is clear of zero.
-    _, work = ops.mlp_backward(net, packed, packed_bwd, raysd, zd, d_rawd, stash, stage=1)
+    # flip between the two implementations (its derivative there is either answer): the flipped entry is excluded by comparing
+    # only where the oracle's pre-activation is clear of zero, and the POINT it belongs to is excluded from every layer below it
+    # (one flipped unit of layer l changes that point's whole gradient row in layers < l).  Such points are rare.
+    _, work = ops.mlp_backward(net, packed, packed_bwd, raysd, zd, d_rawd, stash, stage=1, **bw)
     w = ops.train_views(net, n, S, work=work)
-    def masked_err(got, tapname):
+    flipped = {l: ((v["stash_h"][l].cpu() > 0) != (taps[f"a{l}"].detach() > 0)).any(dim=1) for l in range(D)}      # [P] per layer
+    flipped_d = ((v["stash_g"].cpu() > 0) != (taps["ad"].detach() > 0)).any(dim=1)
+    def masked_err(got, tapname, rows_ok):
         want, pre = taps[tapname].grad, taps[tapname].detach()
-        clear = (pre.abs() > 1e-4).float()
+        clear = (pre.abs() > 1e-4).float() * rows_ok.float()[:, None]
         scale = float(want.abs().max())
         return float(((got.cpu() - want) * clear).abs().max()) / scale
-    assert masked_err(w["delta_d"], "ad") < 1e-5
-    assert rel_err(w["delta_f"], taps["feat"].grad) < 5e-5
+    ok = ~flipped_d
+    assert masked_err(w["delta_d"], "ad", torch.ones(P, dtype=torch.bool)) < 1e-5
+    assert float(((w["delta_f"].cpu() - taps["feat"].grad) * ok.float()[:, None]).abs().max()) < 5e-5 * float(taps["feat"].grad.abs().max())
     for l in range(D - 1, -1, -1):
-        assert masked_err(w["delta_h"][l], f"a{l}") < 1e-4, f"delta_h[{l}]"
+        assert masked_err(w["delta_h"][l], f"a{l}", ok) < 1e-4, f"delta_h[{l}]"
+        ok = ok & ~flipped[l]
+    assert int((~ok).sum()) <= max(2, P // 200), int((~ok).sum())
 
     # 3. full backward: flat parameter gradient in module.parameters() order
-    grads, _ = ops.mlp_backward(net, packed, packed_bwd, raysd, zd, d_rawd, stash)
+    grads, _ = ops.mlp_backward(net, packed, packed_bwd, raysd, zd, d_rawd, stash, **bw)
     off = 0
     for k in ops.param_names(net):
         want = grads_want[k]
@@ -129,7 +151,7 @@ def test_mlp_backward_vs_autograd(D, W, skip, n, S):
     assert off == grads.numel() == ops.param_count(net)
     # the flat vector is allocated uninitialised (torch.empty): every element must be WRITTEN by the weight-gradient kernels
     poison = torch.full((ops.param_count(net),), float("nan"), device=DEV)
-    again, _ = ops.mlp_backward(net, packed, packed_bwd, raysd, zd, d_rawd, stash, grads=poison)
+    again, _ = ops.mlp_backward(net, packed, packed_bwd, raysd, zd, d_rawd, stash, grads=poison, **bw)
     assert again.data_ptr() == poison.data_ptr() and torch.isfinite(poison).all() and torch.equal(poison, grads)
 
 
