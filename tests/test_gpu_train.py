@@ -216,7 +216,9 @@ def _train_setup(D=8, W=256, n=96, Sc=32, Nf=48, seed=0):
     return sd, model, posenc, opts, o, d, t_rand, u, target, cfg
 
 
-def test_train_step_gradients_match_oracle_autograd():
+@pytest.mark.parametrize("f16s", [False, True])
+def test_train_step_gradients_match_oracle_autograd(f16s):
+    """``f16s``: the same step with its three MFMA kernels in split precision, same bars."""
     from nerf_pytorch_paeng_amd import nerf_process as NP, train_path
     sd, model, posenc, opts, o, d, t_rand, u, target, cfg = _train_setup()
     rays = torch.cat([o, d], -1).contiguous()
@@ -231,7 +233,7 @@ def test_train_step_gradients_match_oracle_autograd():
     loss_ref = torch.mean((ref["rgb_c"] - target) ** 2) + torch.mean((ref["rgb_f"] - target) ** 2)      # train.py:60-66
     loss_ref.backward()
 
-    out = train_path.render_train(rays, model, opts, t_rand=t_rand, u=u, z_override=(z_c.to(DEV), z_f))
+    out = train_path.render_train(rays, model, opts, t_rand=t_rand, u=u, z_override=(z_c.to(DEV), z_f), f16s=f16s)
     tgt = target.to(DEV)
     loss = torch.mean((out["rgb_c"] - tgt) ** 2) + torch.mean((out["rgb_f"] - tgt) ** 2)
     loss.backward()
@@ -243,7 +245,7 @@ def test_train_step_gradients_match_oracle_autograd():
         e = rel_err(p.grad, psd[k].grad)
         worst = max(worst, e)
         assert e < 1e-4, (k, e)                                      # relative to the largest entry of that gradient
-    print(f"train step: worst per-tensor gradient error {worst:.2e} (relative to max)")
+    print(f"train step{' (split precision)' if f16s else ''}: worst per-tensor gradient error {worst:.2e} (relative to max)")
 
 
 def test_drop_in_training_loop_runs_and_repacks():
