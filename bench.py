@@ -525,6 +525,18 @@ def worker(args) -> None:
         wg9_tf = 9 * 2.0 * 256 * 256 * n_pts / (wg9_ms * 1e-3) / 1e12
         train["wgrad_256x256"] = {"ms": round(wg_ms, 4), "achieved_TFLOPs": round(wg_tf, 1), "frac_of_f32_mfma_peak": round(wg_tf / PEAK_F32_MFMA_TFLOPS, 4),
                                   "what": "ONE product on its own (mi_nerf_wgrad_product): wgrad_big_kernel over 256 point slices + reduce, hipEvents on the launch stream"}
+        if not args.no_f16s_leg:                                         # the same nine products in split precision: bound by their HBM reads
+            ops.wgrad_products([dlt] * 9, [xin] * 9, n_pts, iters=1, f16s=True)
+            _, _, wgs_ms = ops.wgrad_products([dlt] * 9, [xin] * 9, n_pts, iters=5, timed=True, f16s=True)
+            read_gb = 9 * (2 + 1) * n_pts * 256 * 4 / 1e9               # per product: both operands once + the scale-finding pass over the gradient operand
+            train["wgrad_9x256x256_f16_split"] = {
+                "ms": round(wgs_ms, 4), "ms_per_product": round(wgs_ms / 9, 4), "network_TFLOPs": round(9 * 2.0 * 256 * 256 * n_pts / (wgs_ms * 1e-3) / 1e12, 1),
+                "x_f32_mfma_peak": round(9 * 2.0 * 256 * 256 * n_pts / (wgs_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 3),
+                "roofline": {"bound": "hbm", "achieved": round(read_gb / wgs_ms, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(read_gb / wgs_ms / 8000.0, 4),
+                             "algorithmic_GB": round(read_gb, 2)},
+                "what": "mi_nerf_wgrad_products_f16s: nine products in one launch with operands converted on the fly to f16 hi + lo pairs, dense random operands, "
+                        "including the pass over each gradient operand that finds its scale (the training step takes the scale from d_raw instead and its "
+                        "operands are ReLU-sparse: 2.9 ms per fine-net batch there)"}
         train["wgrad_9x256x256"] = {"ms": round(wg9_ms, 4), "ms_per_product": round(wg9_ms / 9, 4), "achieved_TFLOPs": round(wg9_tf, 1),
                                     "frac_of_f32_mfma_peak": round(wg9_tf / PEAK_F32_MFMA_TFLOPS, 4),
                                     "what": "nine products in one launch (mi_nerf_wgrad_products), the form the backward pass uses for a net's wide layers"}

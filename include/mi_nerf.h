@@ -293,6 +293,13 @@ int mi_nerf_wgrad_product(const float* delta_dev, int ldd, int M, const float* x
 int mi_nerf_wgrad_products(int n, const float* const* delta_dev, const int* ldd, const int* M, const float* const* x_dev, const int* ldx,
                            const int* N, int64_t P, float* const* out_dev, const int* ldo, float* const* bias_dev, void* scratch_dev,
                            size_t scratch_bytes, int iters, float* avg_ms_out, void* stream);
+/* ... in SPLIT PRECISION (wgrad_f16s_kernel: operands converted on the fly to f16 hi + lo pairs, fp32 accumulate, fp32-grade results; the
+ * gradient operands are scaled by a power of two from their largest entry, found by one extra pass over them; ldd[b] == M[b]).  The products
+ * are then bound by the HBM reads of their operands, not by the fp32 matrix rate.  The training step uses the same kernel through
+ * mi_nerf_mlp_backward_mode. */
+int mi_nerf_wgrad_products_f16s(int n, const float* const* delta_dev, const int* ldd, const int* M, const float* const* x_dev, const int* ldx,
+                                const int* N, int64_t P, float* const* out_dev, const int* ldo, float* const* bias_dev, void* scratch_dev,
+                                size_t scratch_bytes, int iters, float* avg_ms, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Either side of the path in the reference's callers.  HBM-bound streaming ops.

@@ -107,6 +107,7 @@ SIGNATURES = {
     "mi_nerf_wgrad_scratch_bytes": (_SZ, []),
     "mi_nerf_wgrad_product": (_I, [_P, _I, _I, _P, _I, _I, _I64, _P, _I, _P, _P, _SZ, _I, C.POINTER(_F), _P]),
     "mi_nerf_wgrad_products": (_I, [_I, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _SZ, _I, C.POINTER(_F), _P]),
+    "mi_nerf_wgrad_products_f16s": (_I, [_I, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _SZ, _I, C.POINTER(_F), _P]),
     "mi_nerf_image_metrics": (_I, [_P, _P, _I64, _P, _P, _SZ, _P]),
     "mi_nerf_nanmax": (_I, [_P, _I64, _P, _P, _SZ, _P]),
     "mi_nerf_to8b": (_I, [_P, _I64, _P, _P, _P]),

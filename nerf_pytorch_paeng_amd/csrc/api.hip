@@ -71,7 +71,7 @@ int pack_apply_bwd_f16s(const mi_nerf_net*, const int32_t*, const float*, void*,
 // use_bf16 of mi_nerf_render_cfg / mi_nerf_time_mlp_rays -> launch shape of the bf16 kernel (0: chosen per launch)
 static inline int bf16_points_per_wave(int use_bf16) { return use_bf16 == 2 ? 64 : (use_bf16 == 3 ? 32 : (use_bf16 == 4 ? 832 : 0)); }
 int wgrad_products(int, const float* const*, const int*, const int*, const float* const*, const int*, const int*, int64_t, float* const*, const int*,
-                   float* const*, void*, size_t, hipStream_t);
+                   float* const*, void*, size_t, hipStream_t, bool);
 int mlp_rays_fp32_stash(const mi_nerf_net*, const void*, const float*, const float*, int64_t, int, float*, float*, float*, float*, unsigned*,
                         unsigned*, hipStream_t);
 int mlp_backward_fp32(const mi_nerf_net*, const void*, const void*, const float*, const float*, int64_t, int, const float*, const void*, void*,
@@ -510,7 +510,13 @@ int mi_nerf_wgrad_products(int n, const float* const* delta, const int* ldd, con
                            int64_t P, float* const* out, const int* ldo, float* const* bias, void* scratch, size_t scratch_bytes, int iters,
                            float* avg_ms, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    return timed_launches(iters, avg_ms, st, [&] { return wgrad_products(n, delta, ldd, M, x, ldx, N, P, out, ldo, bias, scratch, scratch_bytes, st); });
+    return timed_launches(iters, avg_ms, st, [&] { return wgrad_products(n, delta, ldd, M, x, ldx, N, P, out, ldo, bias, scratch, scratch_bytes, st, false); });
+}
+int mi_nerf_wgrad_products_f16s(int n, const float* const* delta, const int* ldd, const int* M, const float* const* x, const int* ldx, const int* N,
+                                int64_t P, float* const* out, const int* ldo, float* const* bias, void* scratch, size_t scratch_bytes, int iters,
+                                float* avg_ms, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    return timed_launches(iters, avg_ms, st, [&] { return wgrad_products(n, delta, ldd, M, x, ldx, N, P, out, ldo, bias, scratch, scratch_bytes, st, true); });
 }
 
 int mi_nerf_selftest_mfma(void* stream) {

@@ -374,10 +374,20 @@ void wgrad_big_kernel(const WgradArgs a) {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long long n, unsigned* __restrict__ out_bits) {
     float m = 0.0f;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) m = __builtin_fmaxf(m, __builtin_fabsf(x[i]));
+    const long long n4 = ((uintptr_t)x & 15) == 0 ? n >> 2 : 0;          // 16-byte pieces, then the tail (or everything) one by one
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const f32x4 v = ((const f32x4*)x)[i];
+        m = __builtin_fmaxf(__builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1]))), __builtin_fmaxf(__builtin_fabsf(v[2]), __builtin_fabsf(v[3])));
+    }
+    for (long long i = 4 * n4 + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) m = __builtin_fmaxf(m, __builtin_fabsf(x[i]));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, o, 64));
     if ((threadIdx.x & 63) == 0 && m == m) atomicMax(out_bits, __float_as_uint(m));      // non-negative floats order like their bit patterns
+}
+static void launch_absmax(const float* x, long long n, unsigned* out_bits, hipStream_t st) {
+    long long blocks = (n / 4 + 255) / 256;
+    blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, n, out_bits);
 }
 // two fp32 values -> a packed f16 pair hi and the packed pair lo = f16(v * s - hi); S: scale by s first (gradient operand)
 template <bool S>
@@ -903,23 +913,35 @@ static int run_wgrad(const float* dlt, int ldd, int M, const float* x, int ldx, 
     return MI_NERF_OK;
 }
 
-size_t wgrad_scratch_bytes() { return WGRAD_PARTIAL_FLOATS * 4; }
+size_t wgrad_scratch_bytes() { return WGRAD_PARTIAL_FLOATS * 4 + 256; }      // partials + the max|delta| word of the split-precision entry
 
 // n (<= 12) wide products over the SAME P points in one launch -- how the backward pass itself runs the nine 256 x 256 products of
 // a network (run_wgrad_batch): the CUs are shared out between the products, so a product is cut into num_cus / n point slices
 // and writes / reduces 1 / n of the partials a stand-alone launch does.
+// f16s: the products in split precision (wgrad_f16s_kernel); the gradient operands are scaled from the largest |delta| entry of the batch,
+// found on the device first (one pass over the deltas: the training step takes it from d_raw instead)
 int wgrad_products(int n, const float* const* dlt, const int* ldd, const int* M, const float* const* x, const int* ldx, const int* N, int64_t P,
-                   float* const* out, const int* ldo, float* const* bias, void* scratch, size_t scratch_bytes, hipStream_t st) {
+                   float* const* out, const int* ldo, float* const* bias, void* scratch, size_t scratch_bytes, hipStream_t st, bool f16s) {
     MN_CHECK_ARG(n >= 1 && n <= WG_MAXB, "between 1 and %d products per launch (got %d)", WG_MAXB, n);
     MN_CHECK_ARG(P >= 1 && dlt && ldd && M && x && ldx && N && out && ldo && scratch, "bad sizes / NULL pointer");
-    MN_CHECK_ARG(scratch_bytes >= WGRAD_PARTIAL_FLOATS * 4, "scratch too small: %zu < %zu", scratch_bytes, WGRAD_PARTIAL_FLOATS * 4);
+    MN_CHECK_ARG(scratch_bytes >= wgrad_scratch_bytes(), "scratch too small: %zu < %zu", scratch_bytes, wgrad_scratch_bytes());
     WideProduct pr[WG_MAXB];
     for (int b = 0; b < n; ++b) {
         MN_CHECK_ARG(dlt[b] && x[b] && out[b] && M[b] > 64 && N[b] > 64 && ldd[b] >= M[b] && ldx[b] >= N[b] && ldo[b] >= N[b],
                      "product %d: the batched entry takes wide products (more than 64 columns on both sides), M=%d N=%d", b, M[b], N[b]);
         pr[b] = WideProduct{dlt[b], ldd[b], M[b], x[b], ldx[b], N[b], out[b], ldo[b], bias ? bias[b] : nullptr};
     }
-    return run_wgrad_batch(pr, n, P, (float*)scratch, st);
+    unsigned* absmax = nullptr;
+    if (f16s) {
+        absmax = (unsigned*)((char*)scratch + WGRAD_PARTIAL_FLOATS * 4);
+        MN_HIP(hipMemsetAsync(absmax, 0, 4, st));
+        for (int b = 0; b < n; ++b) {
+            MN_CHECK_ARG(ldd[b] == M[b], "product %d: the split-precision entry takes gradient operands without row padding (ldd == M)", b);
+            launch_absmax(dlt[b], (long long)P * M[b], absmax, st);
+        }
+        MN_LAUNCH_CHECK("absmax_kernel");
+    }
+    return run_wgrad_batch(pr, n, P, (float*)scratch, st, absmax);
 }
 
 // stand-alone product dW = delta^T x input (+ column sums of delta) for tests and the bench's roofline leg
@@ -996,7 +1018,7 @@ int mlp_backward_fp32(const mi_nerf_net* net, const void* packed_fwd, const void
         MN_CHECK_ARG(W == 256 && !x_dev, "the split-precision backward is built for W=256 and the ray entry point");
         absmax = (unsigned*)((char*)work + L.partial + al256(WGRAD_PARTIAL_FLOATS * 4));
         MN_HIP(hipMemsetAsync(absmax, 0, 4, st));
-        hipLaunchKernelGGL(absmax_kernel, dim3(256), dim3(256), 0, st, d_raw, (long long)P * 4, absmax);
+        launch_absmax(d_raw, (long long)P * 4, absmax, st);
         MN_LAUNCH_CHECK("absmax_kernel");
     }
     if (mode & 2) {

@@ -476,10 +476,10 @@ def wgrad_product(delta: torch.Tensor, M: int, x: torch.Tensor, N: int, P: int, 
 
 
 def wgrad_products(deltas: Sequence[torch.Tensor], xs: Sequence[torch.Tensor], P: int, Ms: Optional[Sequence[int]] = None,
-                   Ns: Optional[Sequence[int]] = None, want_bias: bool = True, iters: int = 1, timed: bool = False):
+                   Ns: Optional[Sequence[int]] = None, want_bias: bool = True, iters: int = 1, timed: bool = False, f16s: bool = False):
     """Several wide products over the same P points in ONE launch (mi_nerf_wgrad_products): out[b] = deltas[b][:P, :M_b]^T xs[b][:P, :N_b]
-    (+ bias[b] = column sums of deltas[b]).  This is how the backward pass runs a network's 256 x 256 products.  Returns
-    (outs, biases, avg_ms)."""
+    (+ bias[b] = column sums of deltas[b]).  This is how the backward pass runs a network's 256 x 256 products.  ``f16s``: in split
+    precision (mi_nerf_wgrad_products_f16s; fp32-grade results, bound by the operands' HBM reads).  Returns (outs, biases, avg_ms)."""
     n = len(deltas)
     if n == 0 or len(xs) != n:
         raise MiNerfError("deltas / xs must be non-empty lists of equal length")
@@ -495,7 +495,7 @@ def wgrad_products(deltas: Sequence[torch.Tensor], xs: Sequence[torch.Tensor], P
     PP, II = C.c_void_p * n, C.c_int * n
     ms = C.c_float(0.0)
     with _guard(dev):
-        check(lib().mi_nerf_wgrad_products(n, PP(*[dev_ptr(d, "delta") for d in deltas]), II(*[d.stride(0) for d in deltas]), II(*Ms),
+        check((lib().mi_nerf_wgrad_products_f16s if f16s else lib().mi_nerf_wgrad_products)(n, PP(*[dev_ptr(d, "delta") for d in deltas]), II(*[d.stride(0) for d in deltas]), II(*Ms),
                                            PP(*[dev_ptr(x, "x") for x in xs]), II(*[x.stride(0) for x in xs]), II(*Ns), int(P),
                                            PP(*[dev_ptr(o) for o in outs]), II(*Ns), PP(*[dev_ptr(b) for b in biases]) if want_bias else None,
                                            dev_ptr(scratch, "scratch", torch.uint8, 16), scratch.numel(), int(iters),

@@ -363,6 +363,14 @@ def test_wgrad_products_batched_entry_equals_the_single_products():
         assert rel_err(o, o1) < 1e-5 and rel_err(b, b1) < 1e-5                   # different slice counts: same sums up to summation order
     with pytest.raises(Exception):
         ops.wgrad_products([deltas[0][:, :32].contiguous()], [xs[0]], P)            # a narrow side: not for the batched entry
+    # the same batch in split precision (wgrad_f16s_kernel through mi_nerf_wgrad_products_f16s): fp32-grade against float64, also with
+    # gradient operands of very different magnitudes in one batch (one scale for the batch, from its largest entry) and tiny ones
+    for scale in (1.0, 1e-6):
+        ds = [d * (scale * (10.0 ** -i)) for i, d in enumerate(deltas)]
+        outs_s, biases_s, _ = ops.wgrad_products(ds, xs, P, f16s=True)
+        for d, x, o, b in zip(ds, xs, outs_s, biases_s):
+            want = d[:P].double().T @ x[:P].double()
+            assert rel_err(o, want) < 2e-5 and rel_err(b, d[:P].double().sum(0)) < 2e-5
 
 
 def test_wgrad_product_beyond_4GiB_operands():
