@@ -532,7 +532,7 @@ def worker(args) -> None:
             train["wgrad_9x256x256_f16_split"] = {
                 "ms": round(wgs_ms, 4), "ms_per_product": round(wgs_ms / 9, 4), "network_TFLOPs": round(9 * 2.0 * 256 * 256 * n_pts / (wgs_ms * 1e-3) / 1e12, 1),
                 "x_f32_mfma_peak": round(9 * 2.0 * 256 * 256 * n_pts / (wgs_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 3),
-                "roofline": {"bound": "hbm", "achieved": round(read_gb / wgs_ms, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(read_gb / wgs_ms / 8000.0, 4),
+                "roofline": {"bound": "hbm", "achieved": round(read_gb / (wgs_ms * 1e-3), 1), "peak": 8000.0, "unit": "GB/s", "frac": round(read_gb / (wgs_ms * 1e-3) / 8000.0, 4),
                              "algorithmic_GB": round(read_gb, 2)},
                 "what": "mi_nerf_wgrad_products_f16s: nine products in one launch with operands converted on the fly to f16 hi + lo pairs, dense random operands, "
                         "including the pass over each gradient operand that finds its scale (the training step takes the scale from d_raw instead and its "
