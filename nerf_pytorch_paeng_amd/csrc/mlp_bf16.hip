@@ -565,8 +565,9 @@ __device__ __forceinline__ void run_phase(const MlpArgsB& a, const PhaseB ph, ch
     unsigned n_tile[NTL];  float nx_r[NTL][6], nx_z;
     auto load_inputs = [&](unsigned it) __attribute__((always_inline)) {
         const unsigned pr = pair_of(it);
+        unsigned my_ray = 0, my_chunk = 0;                        // the tile this lane's own point belongs to (selected, not branched on: a lane-
 #pragma unroll
-        for (int tl = 0; tl < NTL; ++tl) {
+        for (int tl = 0; tl < NTL; ++tl) {                        // dependent branch inside the MFMA stream costs a lone wave more than the select)
             unsigned t = ph.tile0 + (unsigned)NTL * pr + tl;
             n_tile[tl] = t;
             if (t >= ph.tile_end) t = ph.tile_end - 1;            // inactive: recompute the last tile, store nothing
@@ -574,14 +575,15 @@ __device__ __forceinline__ void run_phase(const MlpArgsB& a, const PhaseB ph, ch
             const float* rp = a.rays + (size_t)ray * 6;
 #pragma unroll
             for (int e = 0; e < 6; ++e) nx_r[tl][e] = rp[e];
-            if (tl == (pq >> 1)) {
-                const int sample = (int)chunk * 32 + 16 * (pq & 1) + col;
-                const int sc = sample < a.S ? sample : a.S - 1;
-                if (a.z) nx_z = a.z[(size_t)ray * a.S + sc];
-                else {          // the coarse pass of render_rays: stratified depth drawn here (nerf_process.py:42-60), kept for the compositing
-                    nx_z = stratified_depth((long long)ray, sc, a.S, a.strat_step, a.strat_near, a.strat_far, a.strat_jitter);
-                    if (q4 < NP) a.z_out[(size_t)ray * a.S + sc] = nx_z;      // inactive / clamped lanes rewrite an existing element with its own value
-                }
+            if (tl == 0 || tl == (pq >> 1)) { my_ray = ray; my_chunk = chunk; }
+        }
+        {
+            const int sample = (int)my_chunk * 32 + 16 * (pq & 1) + col;
+            const int sc = sample < a.S ? sample : a.S - 1;
+            if (a.z) nx_z = a.z[(size_t)my_ray * a.S + sc];
+            else {              // the coarse pass of render_rays: stratified depth drawn here (nerf_process.py:42-60), kept for the compositing
+                nx_z = stratified_depth((long long)my_ray, sc, a.S, a.strat_step, a.strat_near, a.strat_far, a.strat_jitter);
+                if (q4 < NP) a.z_out[(size_t)my_ray * a.S + sc] = nx_z;      // inactive / clamped lanes rewrite an existing element with its own value
             }
         }
     };
@@ -974,7 +976,8 @@ static int launch_bf16(MlpArgsB a, long long split, long long n_wtiles, hipStrea
     if (int rc = ensure_lds_opt_in(opt_in, (const void*)kern)) return rc;
     const int n_cus = device_cus();
     const long long wg_a = ((split + NPA / 2 - 1) / (NPA / 2) + NWV - 1) / NWV;
-    const long long wg_b = NPB ? ((n_wtiles - split + NPB / 2 - 1) / (NPB / 2) + NWV - 1) / NWV : 0;
+    constexpr int TPB = NPB ? NPB / 2 : 1;                    // tiles per unit of the second phase (1: no second phase, wg_b unused)
+    const long long wg_b = NPB ? ((n_wtiles - split + TPB - 1) / TPB + NWV - 1) / NWV : 0;
     const long long n_wg = wg_a > wg_b ? wg_a : wg_b;
     const int grid = (int)(n_wg < n_cus ? n_wg : n_cus);
     a.ph[0] = make_phase<NPA, NWV>(a, 0, split, grid);
