@@ -21,7 +21,8 @@ Also on the line: the 800x800 frame time (rows sharded over the ranks, ONE all-g
 over RCCL), `roofline` for the dominant kernel (the fine-network fused MLP launch, hipEvent-timed on its
 launch stream), `bf16` (BASELINE config #5: the same step on the bf16 MFMA variant with its PSNR against the
 fp32 outputs of the same rays, and its own `small_batch`), `f16_split` (the split-precision variant: f16 hi + lo
-operands on the f16 matrix pipe, fp32-grade results; an extra leg, never `value`), `small_batch` (the same step at 256..2048 rays on
+operands on the f16 matrix pipe, fp32-grade results; an extra leg, never `value`; `train.f16_split` is the training step with its
+three MFMA kernels in that mode), `small_batch` (the same step at 256..2048 rays on
 one GPU: what a rank sees under strong scaling) and `cpu_baseline` (the CPU oracle timed on the host cores;
 rank 0, N = 1 only).
 
