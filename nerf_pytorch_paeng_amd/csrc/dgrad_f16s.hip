@@ -26,7 +26,8 @@ struct DArgs {
     unsigned n_wtiles, n_iter, ppr;
     int S, tpr, D;
     const unsigned* absmax_bits;
-};
+    unsigned* delta_absmax_bits;                    // out: max |delta * s| over every stored row piece (bits of a non-negative float): how much of the
+};                                                  // f16 range the scaled chain used (>= 65504: a conversion saturated)
 struct DPair { float y0, y1; unsigned hi, lo; };
 // VAR: 0 plain, 1 ReLU' mask, 2 rank-1 term + mask.  POS: bit position of element 2e of the tile in the pre-shifted mask word.
 template <int VAR, int RH, int RL, int STAGE, int POS>
@@ -54,7 +55,8 @@ __device__ __forceinline__ void dpack_stage(const float h0, const float h1, cons
 }
 // one 16-byte piece of a delta row: the tile's four values of this lane's point, back at true scale
 template <int T>
-__device__ __forceinline__ void delta_store(const DPair& e0, const DPair& e1, float* rowp, float inv_s) {
+__device__ __forceinline__ void delta_store(const DPair& e0, const DPair& e1, float* rowp, float inv_s, float& dmax) {
+    dmax = __builtin_fmaxf(dmax, __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(e0.y0), __builtin_fabsf(e0.y1)), __builtin_fmaxf(__builtin_fabsf(e1.y0), __builtin_fabsf(e1.y1))));
     f32x4 v;
     v[0] = e0.y0 * inv_s; v[1] = e0.y1 * inv_s; v[2] = e1.y0 * inv_s; v[3] = e1.y1 * inv_s;
     asm volatile("global_store_dwordx4 %0, %1, off offset:%2 " MN_F16S_STOREFLAGS "\n\ts_nop 1" ::"v"(rowp), "v"(v), "n"(MT * T * 4) : "memory");
@@ -62,14 +64,14 @@ __device__ __forceinline__ void delta_store(const DPair& e0, const DPair& e1, fl
 // the 24-slot schedule of pack_sched, with the row piece in the free sixth slot of a tile's second pair
 template <int VAR, int SET, int T, int KS, int SUB>
 __device__ __forceinline__ void dpack_sched(const f32x4 (&ph)[NP], const f32x4 (&pl)[NP], DPair (&t)[4], float dn, float up, float nup,
-                                            const unsigned (&msh)[NP][4], const f32x4& dwv, const float (&dsig)[NP], float* const (&rowp)[NP], float inv_s) {
+                                            const unsigned (&msh)[NP][4], const f32x4& dwv, const float (&dsig)[NP], float* const (&rowp)[NP], float inv_s, float& dmax) {
     if constexpr (KS >= 1 && KS <= 6 && SUB >= 2) {
         constexpr int n = 4 * (KS - 1) + (SUB - 2), pair = n / 6, stage = n % 6, p = pair >> 1, e = pair & 1;
         constexpr int POS = 31 - 4 * ((2 * T) & 7) - 2 * e;
         if constexpr (stage < 5)
             dpack_stage<VAR, tile_reg(SET, p, T, 0) + e, tile_reg(SET, p, T, 1) + e, stage, POS>(ph[p][2 * e], ph[p][2 * e + 1], pl[p][2 * e], pl[p][2 * e + 1], t[pair],
                                                                                                  dn, up, nup, msh[p][T >> 2], dwv[2 * e], dwv[2 * e + 1], dsig[p]);
-        else if constexpr (e == 1) delta_store<T>(t[2 * p], t[2 * p + 1], rowp[p], inv_s);
+        else if constexpr (e == 1) delta_store<T>(t[2 * p], t[2 * p + 1], rowp[p], inv_s, dmax);
     }
 }
 // a whole pair in one gap (G0's short jobs)
@@ -133,6 +135,7 @@ void dgrad_f16s_kernel(const DArgs a) {
     const f32x4 czero = {0.f, 0.f, 0.f, 0.f};
     auto csel0 = [&](int) __attribute__((always_inline)) -> const f32x4& { return czero; };
     const int sh4 = 4 * (q4 >> 1);                                  // this lane's nibble of a mask byte pair (see stash_tile)
+    float dmax = 0.0f;                                              // largest scaled gradient this lane stored
     const char* mlds = (const char*)(dwl + W) + wave * (a.D * 1024);
     const unsigned mlds_m0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + RING_BYTES_S + (3 * (W / 2) + W) * 4 + wave * (a.D * 1024);
 
@@ -218,7 +221,7 @@ void dgrad_f16s_kernel(const DArgs a) {
                 auto hook = [&](auto ks_c, auto s_c) __attribute__((always_inline)) {
                     constexpr int ks = decltype(ks_c)::value, sub = decltype(s_c)::value;
                     if constexpr (t > 0 && ks == 0 && sub >= 2) dpack_pair_block<0, t - 1, sub - 2>(ph, pl, pt, dn, up, nup);
-                    if constexpr (t > 0 && ks == 1 && (sub == 2 || sub == 3)) delta_store<t - 1>(pt[2 * (sub - 2)], pt[2 * (sub - 2) + 1], rowp[sub - 2], inv_sc);
+                    if constexpr (t > 0 && ks == 1 && (sub == 2 || sub == 3)) delta_store<t - 1>(pt[2 * (sub - 2)], pt[2 * (sub - 2) + 1], rowp[sub - 2], inv_sc, dmax);
                 };
                 job<t * KG0, KG0, BIG, 0>(ah, al, csel0, bh, bl, aq, smem, ring, lane, hook);
 #pragma unroll
@@ -250,8 +253,8 @@ void dgrad_f16s_kernel(const DArgs a) {
                 DPair pt[4];
                 auto hook = [&](auto ks_c, auto s_c) __attribute__((always_inline)) {
                     constexpr int ks = decltype(ks_c)::value, sub = decltype(s_c)::value;
-                    if constexpr (t == 0) dpack_sched<VARP, SIN, NT - 1, ks, sub>(ph, pl, pt, dn, up, nup, mprev, dwv, dsig, rprev, inv_sc);
-                    else dpack_sched<VARO, SOUT, t - 1, ks, sub>(ph, pl, pt, dn, up, nup, msh, dwv, dsig, rowp, inv_sc);
+                    if constexpr (t == 0) dpack_sched<VARP, SIN, NT - 1, ks, sub>(ph, pl, pt, dn, up, nup, mprev, dwv, dsig, rprev, inv_sc, dmax);
+                    else dpack_sched<VARO, SOUT, t - 1, ks, sub>(ph, pl, pt, dn, up, nup, msh, dwv, dsig, rowp, inv_sc, dmax);
                     // density head^T weights of the tile the NEXT job packs (rank-1 term of G1's output)
                     if constexpr (VARO == 2 && ks == 7 && sub == 2) dwv = *(const f32x4*)(dwl + MT * t + 4 * q4);
                 };
@@ -288,6 +291,9 @@ void dgrad_f16s_kernel(const DArgs a) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) dmax = __builtin_fmaxf(dmax, __shfl_xor(dmax, o, 64));
+    if (lane == 0 && dmax == dmax) atomicMax(a.delta_absmax_bits, __float_as_uint(dmax));
 }
 
 }  // namespace f16s
@@ -312,6 +318,7 @@ int dgrad_f16s(const mi_nerf_net* net, const void* packed_bwd_f16s_dev, const fl
     MN_CHECK_ARG(n_wtiles < (1LL << 30), "too many points for one launch: %lld rays x %d samples", (long long)n_rays, S);
     a.n_wtiles = (unsigned)n_wtiles;
     a.absmax_bits = absmax_dev;
+    a.delta_absmax_bits = const_cast<unsigned*>(absmax_dev) + 1;    // second word of the same slot (zeroed with the first)
     const size_t lds = RING_BYTES_S + (size_t)(3 * 128 + 256) * 4 + (size_t)4 * net->D * 1024;      // ring | heads | per wave: D layers of mask words
     MN_CHECK_ARG(lds <= 160 * 1024, "the split-precision backward-data kernel keeps a tile's ReLU' words of all layers in LDS: D = %d does not fit (D <= 15)", net->D);
     static LdsOptIn opt_in = {};

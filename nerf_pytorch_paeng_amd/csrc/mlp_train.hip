@@ -1017,7 +1017,7 @@ int mlp_backward_fp32(const mi_nerf_net* net, const void* packed_fwd, const void
     if (mode & 3) {
         MN_CHECK_ARG(W == 256 && !x_dev, "the split-precision backward is built for W=256 and the ray entry point");
         absmax = (unsigned*)((char*)work + L.partial + al256(WGRAD_PARTIAL_FLOATS * 4));
-        MN_HIP(hipMemsetAsync(absmax, 0, 4, st));
+        MN_HIP(hipMemsetAsync(absmax, 0, 8, st));              // [0] max|d_raw|, [1] max|delta * s| (written by the split-precision backward-data kernel)
         launch_absmax(d_raw, (long long)P * 4, absmax, st);
         MN_LAUNCH_CHECK("absmax_kernel");
     }

@@ -503,6 +503,15 @@ def wgrad_products(deltas: Sequence[torch.Tensor], xs: Sequence[torch.Tensor], P
     return outs, biases, (float(ms.value) if timed else None)
 
 
+def backward_range(net: Net, n_rays: int, S: int, work: torch.Tensor):
+    """What the last split-precision backward over ``work`` saw (one device -> host read): (max |d_raw|, max |delta * s|), s the power of two
+    that put max|d_raw| in [2^7, 2^8).  The second number is how much of the f16 range the scaled chain used: at or beyond 65504 a conversion
+    saturated (FP16_OVFL: never inf) and the gradients of that step are clipped there."""
+    lay = train_layout(net, n_rays, S)
+    words = work[lay.work_bytes - 256:lay.work_bytes - 248].view(torch.float32).cpu()
+    return float(words[0]), float(words[1])
+
+
 def train_views(net: Net, n_rays: int, S: int, stash: Optional[torch.Tensor] = None, work: Optional[torch.Tensor] = None):
     """Named float views into the stash / backward workspace (staged parity checks)."""
     lay = train_layout(net, n_rays, S)

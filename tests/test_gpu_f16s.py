@@ -351,7 +351,8 @@ def test_f16s_backward_gradient_range(gain, exact, n, S, lego_rays):
     D = 4                                                                       # (77 x 65 = 5005 points: not a multiple of the 32-row load group)
     sd = synthetic.make_state_dict(9, D, 256, skips=())
     sd["model_fine.linear_feat.weight"] = (sd["model_fine.linear_feat.weight"] * gain).astype(np.float32)
-    sd["model_fine.linear_d.weight"] = (sd["model_fine.linear_d.weight"] / gain).astype(np.float32)       # keep the forward in range
+    if exact:                                                                   # (the saturating case amplifies the forward too: it runs in fp32 here)
+        sd["model_fine.linear_d.weight"] = (sd["model_fine.linear_d.weight"] / gain).astype(np.float32)   # compensated: the net amplification is in the backward chain's middle only
     net = weights.infer_net(sd)
     rays = lego_rays[:n].contiguous()
     g = torch.Generator(device=DEV).manual_seed(4)
@@ -362,10 +363,15 @@ def test_f16s_backward_gradient_range(gain, exact, n, S, lego_rays):
     b32 = ops.pack_module(sd, "model_fine.", net, backward=True).to(DEV)
     b16 = ops.pack_module(sd, "model_fine.", net, backward=True, f16s=True).to(DEV)
     g32, _ = ops.mlp_backward(net, blob, b32, rays, z, d_raw, stash)
-    g16, _ = ops.mlp_backward(net, blob, b16, rays, z, d_raw, stash, f16s_wgrad=True, f16s_dgrad=True)
+    g16, work = ops.mlp_backward(net, blob, b16, rays, z, d_raw, stash, f16s_wgrad=True, f16s_dgrad=True)
     assert torch.isfinite(g16).all()
+    top_raw, top_scaled = ops.backward_range(net, n, S, work)                    # what the scaled chain used of the f16 range
+    assert abs(top_raw - float(d_raw.abs().max())) <= 1e-12
     if exact:
         assert float((g16 - g32).abs().max()) <= 1e-4 * float(g32.abs().max())
+        assert 128.0 <= top_scaled < 65504.0, top_scaled
+    else:
+        assert top_scaled >= 65504.0, top_scaled                                 # the saturation is visible to the caller
 
 
 def test_f16s_training_llff_and_two_slabs(monkeypatch):
