@@ -40,6 +40,14 @@ int ensure_lds_opt_in(LdsOptIn& state, const void* kernel);  // hipFuncSetAttrib
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// An MFMA written as an asm statement keeps WRITING its destination tuple until P + 4 wait states after issue (8-pass 16x16x32: 12), and hipcc
+// does not know: an element of the tuple that no later code reads is free for the allocator the moment the statement ends, and whatever
+// lands there first (an address, a shuffle result) is overwritten when the matrix result arrives.  That took down round 3's NOPACK ablation
+// build and sat as a 1-2 wait-state near miss in the shipped STASH kernel (colour tile element 3 vs. a ds_bpermute of
+// finish_masks).  Rule: every tuple with elements the code does not read (density tile: only [3]; colour tile: only [0..2]) is named whole by
+// keep_tuple() at a point >= 12 wait states behind its last MFMA.  tools/mfma_hazard_check.py checks the objects (tests/test_packing_cpu.py).
+__device__ __forceinline__ void keep_tuple(const f32x4& x) { asm volatile("" ::"v"(x)); }
+
 // ---------------------------------------------------------------------------------------------
 // counter-based uniform generator (numpy mirror: oracle/restate.py counter_uniform)
 // ---------------------------------------------------------------------------------------------

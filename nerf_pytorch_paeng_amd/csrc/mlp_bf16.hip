@@ -522,9 +522,13 @@ __device__ __forceinline__ void job(f32x4 (&acc)[NP], CSel csel, BSrc bsrc, u32x
             asm volatile("" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
         });
-        // the C operands are dead for the compiler once the first MFMAs are issued, but the matrix pipe reads them for a few more
-        // cycles: keep their registers out of the allocator's hands until the next group
-        if constexpr (ks == 0) {
+        // the C operands are dead for the compiler once the first MFMAs are issued, but the matrix pipe reads C for up to 7 wait states
+        // after the issue of an 8-pass MFMA (ISA guide 4.5: XDL read srcC -> VALU write): keep their registers out of the allocator's
+        // hands until the END OF GROUP 1 -- >= 2 MFMA issues = 8 wait states behind the last MFMA of group 0.  (Until round 4 this
+        // sat behind group 0, zero wait states after its last MFMA: at the 32-point shape hipcc put the ring's `v_add_u32 fetch_off`
+        // into the bias register right there -- tools/mfma_hazard_check.py; no wrong result was ever observed.)
+        static_assert(KS >= 2, "a job has at least two k-steps");
+        if constexpr (ks == 1) {
             asm volatile("" ::"v"(csel(0)), "v"(csel(1)));
             if constexpr (NP == 4) asm volatile("" ::"v"(csel(2)), "v"(csel(3)));
         }
@@ -839,6 +843,10 @@ __device__ __forceinline__ void run_phase(const MlpArgsB& a, const PhaseB ph, ch
                 auto hook = [&](auto ks_c, auto p_c) __attribute__((always_inline)) {
                     constexpr int ks = decltype(ks_c)::value, p = decltype(p_c)::value;
                     if constexpr (t > 0) pack_sched<NP, true, SIN, t - 1, ks, p>(prev, pt);
+                    if constexpr (t == 0 && ks == 1 && p == NP - 1) {      // the density tile's last MFMA is >= 4 issues back: its tuples may go (keep_tuple, common.h)
+#pragma unroll
+                        for (int pp = 0; pp < NP; ++pp) keep_tuple(hd[pp]);
+                    }
                     if constexpr (t == 0 && ks == 6)            // the density tile finished >= 24 MFMAs ago: keep its one useful register
                         asm volatile("v_mov_b32 %0, %1" : "=v"(dens[p]) : "v"(hd[p][3]));
                     // next pair's rays and depths, two quads BEHIND a ring advance (tail position 162 = slot 5, quad 2): an advance waits for every
@@ -873,6 +881,8 @@ __device__ __forceinline__ void run_phase(const MlpArgsB& a, const PhaseB ph, ch
             }
             // the MFMAs are asm statements: hipcc does not know that `hc` is still in flight (XDL write -> vector-memory read)
             asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+            for (int p = 0; p < NP; ++p) keep_tuple(hc[p]);     // element 3 is never read: whole tuples stay allocated until here
 #pragma unroll
             for (int p = 0; p < NP; ++p)
                 if (valid[p] && q4 == 0) {                      // cat([rgb, density]) NeRF.py:51

@@ -508,6 +508,12 @@ void mlp_f16s_kernel(const Args a) {
             }
         }
         // ---- layer 0: 16 jobs of 2 k-steps over gamma(x) (VGPR fragments), output into set 0 -------------------------------------------
+        if constexpr (STASH) {                                   // (re-stated here so that the eight words are not live across the prologue, the kernel's register peak)
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) mw[p][k] = 0u;
+        }
         {
             const float* b0 = side + a.o_bias_trunk + 4 * q4;
             cin = *(const f32x4*)b0;
@@ -619,6 +625,9 @@ void mlp_f16s_kernel(const Args a) {
                     if constexpr (t > 0) pack_sched<true, SIN, t - 1, ks, sub>(ph, pl, pt, dn, up, nup);
                     if constexpr (STASH && t > 0 && ks == 6 && (sub == 4 || sub == 5))      // (group 7's gaps carry this layer's own loads)
                         stash_tile<true, true, t - 1>(pt[2 * (sub - 4)], pt[2 * (sub - 4) + 1], rowp[sub - 4], mw[sub - 4], nib_sh);
+                    if constexpr (t == 0 && ks == 0 && sub == 3) {          // the density tile's last MFMA is 4 issues (16 wait states) back: its tuples may go (keep_tuple, common.h)
+                        keep_tuple(hdh[0]); keep_tuple(hdh[1]); keep_tuple(hdl[0]); keep_tuple(hdl[1]);
+                    }
                     if constexpr (t == 0 && ks == 7 && sub >= 4)            // the density tile finished >= 40 MFMAs ago: keep its one useful value
                         asm volatile("v_fma_f32 %0, %1, %3, %2" : "=v"(dens[sub - 4]) : "v"(hdl[sub - 4][3]), "v"(hdh[sub - 4][3]), "s"(dn));
                     if constexpr (t == MN_F16S_PF_T && ks == MN_F16S_PF_KS && sub == 3) load_inputs(it + 1 < a.n_iter ? it + 1 : it);      // next unit's ray and depths
@@ -645,10 +654,13 @@ void mlp_f16s_kernel(const Args a) {
                         stash_tile<true, true, NT / 2 - 1>(pt[2 * (sub - 2)], pt[2 * (sub - 2) + 1], rowp[sub - 2], mw[sub - 2], nib_sh);
                 };
                 job<200, KH / 2, TAIL_USED_P, TAIL_PAIRS - TAIL_USED_P>(hch, hcl, cselh, bh_in, bl_in, aq, smem, ring, lane, hook);
-                if constexpr (STASH) finish_masks<2>(mw, a.mask_g + (size_t)tile_cur * 128, col, q4, tile_active);
             }
-            // the MFMAs are asm statements: hipcc does not know that the colour tile is still in flight (XDL write -> VALU read)
-            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+            // the MFMAs are asm statements: hipcc does not know that the colour tile is still in flight (XDL write -> VALU read), nor that
+            // the tiles' fourth registers, which nothing reads, are still to be WRITTEN: the whole tuples pass through the wait statement
+            // (keep_tuple, common.h), and nothing else sits between the job and it
+            asm volatile("s_nop 15\n\ts_nop 15" : "+v"(hcl[0]), "+v"(hcl[1]) : "v"(hch[0][3]), "v"(hch[1][3]) : "memory");
+            // (behind the colour tile's window, not inside it: until round 4 a shuffle result landed in a tile's unread fourth register)
+            if constexpr (STASH) finish_masks<2>(mw, a.mask_g + (size_t)tile_cur * 128, col, q4, tile_active);
 #pragma unroll
             for (int p = 0; p < NP; ++p)
                 if (valid[p] && q4 == 0) {                      // cat([rgb, density]) NeRF.py:51

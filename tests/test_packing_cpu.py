@@ -234,8 +234,7 @@ def test_fragment_file_kernels_own_m0_and_the_agpr_file(src, mfma_name, min_mfma
     import re
     import subprocess
     from nerf_pytorch_paeng_amd import build
-    obj = os.path.join(build.CSRC, "build", src + ".o")
-    assert os.path.exists(obj), "build the library first"
+    obj = build.ensure_object(src)
     objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
     if not os.path.exists(objdump):
         pytest.skip("llvm-objdump not found")
@@ -261,6 +260,63 @@ def test_fragment_file_kernels_own_m0_and_the_agpr_file(src, mfma_name, min_mfma
     for l in lines:                                                               # AGPRs appear only as MFMA B operands / accvgpr_write targets
         if re.search(r"\ba\[?\d", l):
             assert l.startswith("v_accvgpr_write_b32 a") or l.startswith(mfma_name + " v["), l
+
+
+@pytest.mark.parametrize("src,min_mfma", [("mlp_bf16.hip", 4000), ("mlp_f16s.hip", 6000), ("mlp_f16s_stash.hip", 6000), ("dgrad_f16s.hip", 3000),
+                                          ("mlp_fp32.hip", 800), ("mlp_train.hip", 60)])
+def test_mfma_destinations_and_c_operands_are_left_alone_for_their_wait_states(src, min_mfma):
+    """An MFMA written as an asm statement gets none of hipcc's software wait states: nothing may read or write its destination tuple within
+    P + 4 wait states of its issue, no VALU may write its C operand within 7 / 13 (ISA guide 4.5; cdna_hip_programming.md 5.7 item 2).  Round 3's
+    NOPACK ablation build of the f16s kernel page-faulted on exactly this (dead accumulators -> their registers reused for the DMA address and
+    the ring's fetch offset -> overwritten by the late matrix write), and the audit that followed found two near misses in shipped kernels
+    (DESIGN 3.4).  tools/mfma_hazard_check.py walks the disassembly; the builtin-MFMA kernels (fp32, training) ride along as a check of the checker."""
+    import os
+    import sys
+    from nerf_pytorch_paeng_amd import build
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import mfma_hazard_check as H
+    obj = build.ensure_object(src)
+    if not os.path.exists(H.OBJDUMP):
+        pytest.skip("llvm-objdump not found")
+    seen = 0
+    for name, ins in H.kernels_of(H.device_asm(obj)).items():
+        n, bad = H.check(ins)
+        seen = max(seen, n)
+        assert not bad, f"{name}: {len(bad)} pairs, first: {bad[:3]}"
+    assert seen > min_mfma
+
+
+def test_mfma_hazard_checker_sees_a_planted_hazard():
+    """The checker on hand-made listings: the NOPACK build's two faulting patterns, a load-return write, a clean stream."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import mfma_hazard_check as H
+
+    def listing(*body):
+        return H.kernels_of("0000000000001900 <k>:\n" + "".join(f"\t{b}    // 00: 00\n" for b in body))["k"]
+    mf = "v_mfma_f32_16x16x32_f16 v[54:57], v[80:83], a[120:123], v[54:57]"
+    # 1. the DMA address pair computed into a pending destination
+    n, bad = H.check(listing(mf, "ds_read_b128 v[0:3], v72", "s_nop 0", "v_lshl_add_u64 v[54:55], v[66:67], 0, s[10:11]", "global_load_lds_dwordx4 v[54:55], off"))
+    assert n == 1 and any(b.startswith("WAW") for b in bad) and any(b.startswith("RAW") for b in bad)
+    # 2. the ring's fetch offset behind a barrier: instruction counts, not time, are what the check sees
+    n, bad = H.check(listing("v_mfma_f32_16x16x32_f16 v[12:15], v[44:47], v[56:59], v[12:15]", "s_waitcnt vmcnt(8)", "s_barrier", "v_add_u32_e32 v12, 0x8000, v74"))
+    assert len(bad) == 1 and bad[0].startswith("WAW")
+    # 3. a shuffle result landing in the unread element of the colour tile (the shipped STASH kernel until round 4)
+    n, bad = H.check(listing("v_mfma_f32_16x16x32_f16 v[76:79], v[104:107], a[88:91], v[76:79]", "ds_bpermute_b32 v79, v188, v85"))
+    assert len(bad) == 1
+    # 4. VALU write of a C operand right behind the MFMA (the shipped bf16 32-point shape until round 4); legal after 7 wait states
+    c = "v_mfma_f32_16x16x32_bf16 v[22:25], v[36:39], a[32:35], v[14:17]"
+    assert H.check(listing(c, "v_add_u32_e32 v14, 0x8000, v54"))[1]
+    assert not H.check(listing(c, "s_nop 6", "v_add_u32_e32 v14, 0x8000, v54"))[1]
+    # 5. far enough: 12 wait states; an accumulate chain through C needs none; intervening MFMAs count their issue interval (4)
+    assert not H.check(listing(mf, "s_nop 11", "v_mov_b32_e32 v54, v1"))[1]
+    assert H.check(listing(mf, "s_nop 10", "v_mov_b32_e32 v54, v1"))[1]
+    assert not H.check(listing(mf, mf, mf))[1]
+    other = "v_mfma_f32_16x16x32_f16 v[0:3], v[80:83], a[0:3], v[0:3]"
+    assert not H.check(listing(mf, other, other, other, "v_mov_b32_e32 v9, v54"))[1]
+    assert H.check(listing(mf, other, other, "v_mov_b32_e32 v9, v54"))[1]
+    assert H.check(listing(mf, other, other, other, "v_mov_b32_e32 v9, v54"), strict=True)[1]
 
 
 @pytest.mark.parametrize("backward", [False, True])

@@ -1,6 +1,8 @@
 """A/B timing of the fused MLP kernel: the shipped library against a variant built with
 `python -m nerf_pytorch_paeng_amd.build --variant TAG -D...`, alternating in ONE process on ONE box (box-to-box
-variance is ~0.5 %, more than most single changes):  python tools/ab_probe.py TAG[,TAG2,...] [rounds] [bf16] [points_per_wave] [rays] [S]"""
+variance is ~0.5 %, more than most single changes):  python tools/ab_probe.py TAG[,TAG2,...] [rounds] [bf16] [points_per_wave] [rays] [S]
+A TAG may carry its defines, `nodma:-DMN_F16S_NODMA`: variants live in build_scratch/, which does not travel to the GPU box, so a missing one is
+built where the probe runs (~1.5 min of box time each)."""
 import ctypes as C
 import os
 import sys
@@ -28,8 +30,11 @@ z = torch.sort(torch.rand(N, S, device=dev) * 4 + 2, -1)[0]
 raw = torch.empty(N, S, 4, device=dev)
 
 libs = {"shipped": _lib.lib()}
-for tg in tag.split(","):
-    h = C.CDLL(os.path.join(os.path.dirname(_lib.LIB_PATH), f"libmi_nerf_{tg}.so"))
+from nerf_pytorch_paeng_amd import build as _build
+for spec in tag.split(","):
+    tg, _, defs = spec.partition(":")
+    path = _build.build_variant(tg, [d for d in defs.split(":") if d]) if defs or not os.path.exists(_build.variant_path(tg)) else _build.variant_path(tg)
+    h = C.CDLL(path)
     for name, (res, args) in _lib.SIGNATURES.items():
         fn = getattr(h, name)
         fn.restype, fn.argtypes = res, args

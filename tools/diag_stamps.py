@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Run the fused MLP once through the MN_DIAG build (libmi_nerf_diag.so) and print where a tile's cycles go.
+"""Run the fused MLP once through the MN_DIAG build (build_scratch/libmi_nerf_diag.so) and print where a tile's cycles go.
 Diagnostic only: the stamped build serialises around every stamp; read its SHARES, never its run time."""
 import os
 import sys
@@ -10,7 +10,8 @@ import torch  # noqa: E402
 
 from nerf_pytorch_paeng_amd import _lib  # noqa: E402
 
-_lib.LIB_PATH = os.path.join(ROOT, "nerf_pytorch_paeng_amd", "libmi_nerf_diag.so")
+from nerf_pytorch_paeng_amd import build as _build
+_lib.LIB_PATH = _build.build_diag_library()          # build_scratch/libmi_nerf_diag.so, built here when missing
 from nerf_pytorch_paeng_amd import ops, synthetic, weights  # noqa: E402
 
 dev = torch.device("cuda:0")

@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of wgrad_big_kernel variants on one box: shipped library vs nerf_pytorch_paeng_amd/libmi_nerf_wgsync.so (a --variant build),
+# A/B of wgrad_big_kernel variants on one box: shipped library vs build_scratch/libmi_nerf_wgsync.so (a --variant build),
 # training-step time interleaved x3, then FETCH_SIZE of the weight-gradient launches for both
 export TMPDIR=/tmp
 mkdir -p gpurun_out/r3r
