@@ -157,6 +157,65 @@ def bf16_stream(blob, n_points: int, kernel_ms: float) -> dict:
             "chip_lds_dma_rate_TBps_measured": LDS_DMA_CHIP_TBPS, "frac_of_lds_dma_rate": round(tbps / LDS_DMA_CHIP_TBPS, 3)}
 
 
+def collective_block(dist, mdist, torch, dev, backend, rank, world, H, W, K, pose, packed, opts, bf16, rgb_last, disp_last) -> dict:
+    """The `collective` object of an N > 1 line (every rank calls this; the dict is the same on all of them).
+
+    backend / world_size        what torch.distributed itself reports (backend "nccl" IS RCCL on ROCm)
+    ranks                       per rank: host, device ordinal, device name, PCI bus id -- all-gathered, so N distinct GPUs are visible in the line
+    distinct_devices            number of distinct (host, PCI bus id) pairs among them (N on a real run; 1 in a gloo rehearsal on one GPU)
+    all_gather_ms               ONE gather_tiles() of this frame's [rows_local * W, 4] tile: hipEvents on the stream the collective is
+                                ordered on (torch's current stream), median of 10 after 2 warm-ups, max over ranks; + the bytes it moves
+    frame_equal_across_ranks    the assembled frame of the last timed pose has the same 64-bit checksum on every rank (all-reduce MIN of
+                                an equality flag against rank 0's checksum)
+    neighbour_tile_recomputed_equal   every rank re-renders the row block of rank (r + 1) % N on ITS OWN GPU and compares it bit for bit
+                                with that block of the gathered frame: the gather put each tile where it belongs, and the frame does
+                                not depend on which GPU rendered which rows (dist.py's bit-identity claim, checked on the hardware)"""
+    import statistics
+    cdev = dev if backend == "nccl" else torch.device("cpu")
+    props = torch.cuda.get_device_properties(dev)
+    bus = getattr(props, "pci_bus_id", None)
+    me = {"rank": rank, "host": socket.gethostname(), "device": f"cuda:{dev.index}", "name": props.name,
+          "pci_bus_id": None if bus is None else int(bus), "cus": int(props.multi_processor_count)}
+    ranks = [None] * world
+    dist.all_gather_object(ranks, me)
+    pose_last = pose
+    local = mdist.render_shard(H, W, K, pose_last, packed, opts, world, rank, seed=0, bf16=bf16)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    times = []
+    for i in range(12):
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        ev[0].record()
+        full = mdist.gather_tiles(local, H, W, force_collective=True)
+        ev[1].record()
+        torch.cuda.synchronize(dev)
+        if i >= 2:
+            times.append(ev[0].elapsed_time(ev[1]))
+    tm = torch.tensor([statistics.median(times)], dtype=torch.float64, device=cdev)
+    dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+
+    def checksum(t):                                       # order-sensitive 64-bit sum over the fp32 bit patterns
+        b = t.contiguous().view(torch.int32).to(torch.int64).reshape(-1)
+        return int((b * (torch.arange(b.numel(), device=b.device, dtype=torch.int64) % 1000003 + 1)).sum().item())
+
+    frame_last = torch.cat([rgb_last.reshape(H * W, 3), disp_last.reshape(H * W, 1)], -1)
+    cs = torch.tensor([checksum(frame_last)], dtype=torch.int64, device=cdev)
+    cs0 = cs.clone()
+    dist.broadcast(cs0, src=0)
+    nb = (rank + 1) % world
+    r0, nr = mdist.shard_rows(H, world, nb)
+    mine = mdist.render_shard(H, W, K, pose_last, packed, opts, world, nb, seed=0, bf16=bf16)
+    flags = torch.tensor([int(cs.item() == cs0.item()), int(torch.equal(mine, full[r0 * W:(r0 + nr) * W]))], dtype=torch.int32, device=cdev)
+    dist.all_reduce(flags, op=dist.ReduceOp.MIN)
+    max_rows = (H + world - 1) // world
+    return {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks": ranks,
+            "distinct_devices": len({(r["host"], r["device"] if r["pci_bus_id"] is None else r["pci_bus_id"]) for r in ranks}),
+            "all_gather_ms": round(float(tm.item()), 4), "all_gather_bytes_per_rank": max_rows * W * 4 * 4, "all_gather_bytes_assembled": world * max_rows * W * 4 * 4,
+            "all_gather_timing": "hipEvents around dist.gather_tiles on torch's current stream (the collective is ordered on it), median of 10, max over ranks",
+            "frame_checksum_rank0": int(cs0.item()), "frame_equal_across_ranks": bool(flags[0].item()),
+            "neighbour_tile_recomputed_equal": bool(flags[1].item())}
+
+
 def worker(args) -> None:
     import numpy as np
     import torch
@@ -454,6 +513,11 @@ def worker(args) -> None:
             f16s_leg["frame_psnr_vs_f32_dB"] = round(-10.0 * math.log10(max(float(torch.mean((rgb_s - rgb) ** 2)), 1e-20)), 2)
             f16s_leg["frame_pixels_beyond_1_grey_level"] = int(((rgb_s - rgb).abs().amax(-1) > 1.0 / 255.0).sum())
 
+    # ---- N > 1: what the collective saw, so that the first multi-GPU run verifies itself from the driver's record ------------------------
+    collective = None
+    if use_dist and args.frames > 0:
+        collective = collective_block(dist, mdist, torch, dev, backend, rank, world, H, W, K, pose, packed, opts, args.bf16, rgb, disp)
+
     # ---- training step: forward + backward + Adam on this rank's 4096-ray batch --------------
     train = None
     if train_steps > 0 and not args.bf16:
@@ -629,8 +693,10 @@ def worker(args) -> None:
             "frac_of_roofline_end_to_end": round(head_value / world * FLOP_PER_RAY / 1e12 / peak, 4),
             "roofline": roofline,
         }
+        if collective is not None:
+            line["collective"] = collective
         if solo:
-            line["solo_rank"] = {"rank": rank, "of": world, "what": "BENCH_SOLO_RANK=1: this rank's share of the run timed alone (no process group, "
+            line["solo_rank"] = {"rank": rank, "of": world, "n_gpus_measured": 1, "what": "BENCH_SOLO_RANK=1: this rank's share of the run timed alone (no process group, "
                                  "no gather); `value` assumes every rank takes as long as this one"}
         if not args.bf16:
             line["frac_of_f32_mfma_roofline_end_to_end"] = line["frac_of_roofline_end_to_end"]

@@ -21,23 +21,25 @@ int hip_fail(hipError_t e, const char* what) {
 
 // ---- per-device launch state -----------------------------------------------------------------------
 int device_cus() {
-    static int cus[MN_MAX_DEVICES] = {};
+    static std::atomic<int> cus[MN_MAX_DEVICES] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 256;
-    int& c = cus[dev & (MN_MAX_DEVICES - 1)];
+    std::atomic<int>& slot = cus[dev & (MN_MAX_DEVICES - 1)];
+    int c = slot.load(std::memory_order_relaxed);
     if (c <= 0) {
         hipDeviceProp_t prop;
         c = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+        slot.store(c, std::memory_order_relaxed);
     }
     return c;
 }
 int ensure_lds_opt_in(LdsOptIn& state, const void* kernel) {
     int dev = 0;
     MN_HIP(hipGetDevice(&dev));
-    bool& done = state.done[dev & (MN_MAX_DEVICES - 1)];
-    if (!done) {
+    std::atomic<bool>& done = state.done[dev & (MN_MAX_DEVICES - 1)];
+    if (!done.load(std::memory_order_acquire)) {
         MN_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        done = true;
+        done.store(true, std::memory_order_release);
     }
     return MI_NERF_OK;
 }

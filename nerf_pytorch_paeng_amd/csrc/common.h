@@ -1,5 +1,6 @@
 // common.h -- error plumbing and small device helpers shared by all translation units.
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -32,8 +33,11 @@ int hip_fail(hipError_t e, const char* what);
 
 // Per-DEVICE launch state (a process may drive several GPUs: the 160 KB dynamic-LDS opt-in is an attribute of the function ON a
 // device, and the CU count is a property of the device): small arrays indexed by the current device ordinal.
+// The entry points are re-entrant per stream and callable from several host threads: the only state the library keeps between calls are
+// these per-device words, atomics written with the same value by whoever gets there first (hipFuncSetAttribute is idempotent), and the
+// thread-local error text.  tests/test_gpu_streams.py.
 constexpr int MN_MAX_DEVICES = 64;
-struct LdsOptIn { bool done[MN_MAX_DEVICES]; };
+struct LdsOptIn { std::atomic<bool> done[MN_MAX_DEVICES]; };
 int device_cus();                                             // multiProcessorCount of the current device (cached per device)
 int ensure_lds_opt_in(LdsOptIn& state, const void* kernel);  // hipFuncSetAttribute(MaxDynamicSharedMemorySize = 160 KB), once per device
 

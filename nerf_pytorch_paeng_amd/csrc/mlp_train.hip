@@ -984,7 +984,13 @@ int mlp_backward_fp32(const mi_nerf_net* net, const void* packed_fwd, const void
     MN_CHECK_ARG(!x_dev || (S == 32 && n_rows >= 0 && n_rays == (n_rows + 31) / 32), "embedded mode wants (n_rays, S) = (ceil(n / 32), 32)");
     mi_nerf_train_layout L;
     if (int rc = train_layout(net, n_rays, S, &L)) return rc;
-    if (P == 0) return MI_NERF_OK;
+    if (P == 0) {                                                  // an empty batch: the gradient of nothing is zero (what autograd gives), never the caller's uninitialised buffer
+        if (grads && stage != 1) {
+            MN_CHECK_ARG(net->D >= 1 && net->D <= 16 && (net->W == 128 || net->W == 256), "unsupported network D=%d W=%d", net->D, net->W);
+            MN_HIP(hipMemsetAsync(grads, 0, (size_t)make_param_offsets(net->D, net->W, net->skip, net->L_x, net->L_d).total * 4, st));
+        }
+        return MI_NERF_OK;
+    }
     MN_CHECK_ARG(packed_fwd && packed_bwd && (x_dev || (rays && z)) && d_raw && stash && work && grads, "NULL device pointer");
     MN_CHECK_ARG(work_bytes >= L.work_bytes, "workspace too small: %zu < %zu", work_bytes, L.work_bytes);
     const int D = net->D, W = net->W;

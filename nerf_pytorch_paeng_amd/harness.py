@@ -370,7 +370,9 @@ def train(idx, i_train, images, gt_cam_param, hw, model, criterion, posenc, opti
     full-frame ``make_o_d``); render with gradients (train.py:53); ``criterion`` on the coarse and fine colours
     (train.py:60-66); ``loss.backward(); optimizer.step()`` (train.py:69-70); checkpoint in the reference's format every
     ``opts.idx_save`` steps when ``log_dir`` is given (train.py:105-114).  ``vis`` (visdom) is accepted and unused.
-    Returns the losses and PSNRs as 0-dim device tensors (no host synchronisation)."""
+    Returns the losses and PSNRs as 0-dim device tensors (no host synchronisation).  With ``opts.precision == "f16s"`` the dict also
+    carries ``f16s`` = train_path.f16s_status(model) every ``opts.idx_print`` steps (one device -> host read): the share of the f16 range
+    the scaled backward used and the packer's out-of-range count; the training path itself raises when either says a step was clipped."""
     model.train()
     img_h, img_w = hw
     gt_intrinsic, gt_extrinsic = gt_cam_param
@@ -397,6 +399,9 @@ def train(idx, i_train, images, gt_cam_param, hw, model, criterion, posenc, opti
     out["loss"] = loss.detach()
     loss.backward()                                                                           # train.py:69
     optimizer.step()                                                                          # train.py:70
+    if _precision(opts)["f16s"] and idx % int(getattr(opts, "idx_print", 0) or 100) == 0:
+        from . import train_path
+        out["f16s"] = train_path.f16s_status(model, reset=False)
     if log_dir is not None and idx % int(getattr(opts, "idx_save", 0) or (1 << 62)) == 0 and idx > 0:
         save_path = os.path.join(log_dir, opts.exp_name)
         os.makedirs(save_path, exist_ok=True)

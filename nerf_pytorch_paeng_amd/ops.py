@@ -404,7 +404,8 @@ def mlp_backward(net: Net, packed: torch.Tensor, packed_bwd: torch.Tensor, rays:
     ``f16s_wgrad``: the W-wide weight-gradient products run in split precision (fp32-grade results, HBM-bound instead of MFMA-bound).
     ``f16s_dgrad``: the backward-data chain runs in split precision; ``packed_bwd`` is then the blob of pack_apply_f16s(..., backward=True).
     The weight-gradient kernels write EVERY element of the flat vector (each parameter block is the output of exactly one product's
-    reduction), so it is allocated uninitialised; ``grads`` lets a test pass a poisoned buffer to check exactly that."""
+    reduction), so it is allocated uninitialised; ``grads`` lets a test pass a poisoned buffer to check exactly that.  Two calls write
+    nothing of it and say so: ``stage=1`` (deltas only: ``grads`` comes back as None) and an empty batch (zero-filled by the library)."""
     n, S = z.shape
     if tuple(d_raw.shape) != (n, S, 4) or tuple(rays.shape) != (n, 6):
         raise MiNerfError(f"d_raw must be {(n, S, 4)} and rays {(n, 6)}, got {tuple(d_raw.shape)} / {tuple(rays.shape)}")
@@ -421,7 +422,7 @@ def mlp_backward(net: Net, packed: torch.Tensor, packed_bwd: torch.Tensor, rays:
                                               dev_ptr(rays, "rays"), dev_ptr(z, "z"), n, S, dev_ptr(d_raw, "d_raw", align=16),
                                               dev_ptr(stash, "stash", torch.uint8, 16), dev_ptr(work, "work", torch.uint8, 16), work.numel(),
                                               dev_ptr(grads, "grads"), int(stage), (1 if f16s_wgrad else 0) | (2 if f16s_dgrad else 0), stream_ptr(dev)), "mi_nerf_mlp_backward_mode")
-    return grads, work
+    return (None if stage == 1 else grads), work
 
 
 def mlp_embedded_train(net: Net, packed: torch.Tensor, x: torch.Tensor):
@@ -510,6 +511,12 @@ def backward_range(net: Net, n_rays: int, S: int, work: torch.Tensor):
     lay = train_layout(net, n_rays, S)
     words = work[lay.work_bytes - 256:lay.work_bytes - 248].view(torch.float32).cpu()
     return float(words[0]), float(words[1])
+
+
+def backward_range_words(net: Net, n_rays: int, S: int, work: torch.Tensor) -> torch.Tensor:
+    """The same two words as a device view (float32 [2]) -- for callers that fold them on the device instead of reading them (train_path)."""
+    lay = train_layout(net, n_rays, S)
+    return work[lay.work_bytes - 256:lay.work_bytes - 248].view(torch.float32)
 
 
 def train_views(net: Net, n_rays: int, S: int, stash: Optional[torch.Tensor] = None, work: Optional[torch.Tensor] = None):

@@ -26,6 +26,15 @@ from .weights import _param_shape, infer_net
 # rays per autograd node: the activation stash is ~9.9 KB per sample point (W = 256, D = 8)
 MAX_TRAIN_RAYS = 16384
 
+# The split-precision backward runs on d_raw * s with ~256x of f16 headroom (FP16_OVFL: conversions clip at 65504, never inf), and the
+# split-precision packers cannot represent a weight beyond the f16 range: both failure modes are silent on the device.  Every f16s backward
+# folds what it saw into three device words of the model's state (no host synchronisation); they are READ -- one device -> host copy -- on
+# the first such backward and then every F16S_CHECK_EVERY-th, and a saturated chain or an unrepresentable weight then raises (or warns, by
+# F16S_ON_SATURATION).  f16s_status(model) reads them on demand; harness.train() returns them in its dict.
+F16S_CHECK_EVERY = 50
+F16S_ON_SATURATION = "raise"          # or "warn"
+F16_MAX = 65504.0
+
 
 class _TrainState:
     """Per-model constants of the training path: network shape and the device-side pack maps."""
@@ -39,6 +48,8 @@ class _TrainState:
         self.map_bwd = ops.pack_map(self.net, True).to(device)
         self._map_f16s = None
         self.f16s_out_of_range = None          # device counter: weights the split-precision packer could not represent (NaN / beyond f16)
+        self.f16s_range = None                 # device [2]: running max of (max |d_raw|, max |delta * s|) over the f16s backwards since the last read
+        self.f16s_backwards = 0                # f16s backward launches so far (host count; sets the read cadence)
 
     def map_f16s(self) -> torch.Tensor:
         """Gather map of the split-precision blob, built on first use (f16s=True training forward)."""
@@ -46,7 +57,40 @@ class _TrainState:
             self._map_f16s = ops.pack_map_f16s(self.net).to(self.device)
             self._map_bwd_f16s = ops.pack_map_f16s(self.net, backward=True).to(self.device)
             self.f16s_out_of_range = torch.zeros(1, dtype=torch.int32, device=self.device)
+            self.f16s_range = torch.zeros(2, dtype=torch.float32, device=self.device)
         return self._map_f16s
+
+    def note_f16s_backward(self, work: torch.Tensor, n_rays: int, S: int) -> None:
+        """Fold the range words the split-precision backward left in ``work`` into the running maximum (device side), and at the cadence
+        read them and complain."""
+        torch.maximum(self.f16s_range, ops.backward_range_words(self.net, n_rays, S, work), out=self.f16s_range)
+        self.f16s_backwards += 1
+        if self.f16s_backwards == 1 or self.f16s_backwards % max(1, int(F16S_CHECK_EVERY)) == 0:
+            self.check_f16s()
+
+    def read_f16s(self, reset: bool = True) -> Dict[str, float]:
+        """One device -> host read of the three words: {"max_abs_d_raw", "max_abs_delta_scaled", "weights_out_of_range", "saturated"}."""
+        if self.f16s_range is None:
+            return {"max_abs_d_raw": 0.0, "max_abs_delta_scaled": 0.0, "weights_out_of_range": 0, "saturated": False}
+        both = torch.cat([self.f16s_range, self.f16s_out_of_range.float()]).cpu()
+        if reset:
+            self.f16s_range.zero_()
+            self.f16s_out_of_range.zero_()
+        d, ds, oor = float(both[0]), float(both[1]), int(both[2])
+        return {"max_abs_d_raw": d, "max_abs_delta_scaled": ds, "weights_out_of_range": oor, "saturated": bool(ds >= F16_MAX or ds != ds or oor > 0)}
+
+    def check_f16s(self) -> Dict[str, float]:
+        r = self.read_f16s()
+        if r["saturated"]:
+            msg = (f"split-precision training step out of range: max |delta * s| = {r['max_abs_delta_scaled']:.4g} (f16 max {F16_MAX:.0f}; max |d_raw| = "
+                   f"{r['max_abs_d_raw']:.4g}), {r['weights_out_of_range']} weight(s) beyond the f16 range, over up to {F16S_CHECK_EVERY} backward launches: "
+                   f"their gradients were clipped.  Train with the fp32 backward (precision 'fp32') or scale the loss down.")
+            if F16S_ON_SATURATION == "warn":
+                import warnings
+                warnings.warn(msg, RuntimeWarning, stacklevel=3)
+            else:
+                raise MiNerfError(msg)
+        return r
 
     def map_bwd_f16s(self) -> torch.Tensor:
         self.map_f16s()
@@ -136,7 +180,9 @@ class _RenderTrain(torch.autograd.Function):
             f16s_dgrad = f16s and net.D <= 15              # the split-precision chain keeps a tile's ReLU' words of all layers in LDS
             blob_b = ops.pack_apply_f16s(net, st.map_bwd_f16s(), flat, st.f16s_out_of_range, backward=True) if f16s_dgrad else ops.pack_apply(st.map_bwd, flat)
             d_raw = ops.composite_backward(raw, z, rays, g_rgb.contiguous().float())
-            grads, _ = ops.mlp_backward(net, blob, blob_b, rays, z, d_raw, stash, f16s_wgrad=f16s, f16s_dgrad=f16s_dgrad)
+            grads, work = ops.mlp_backward(net, blob, blob_b, rays, z, d_raw, stash, f16s_wgrad=f16s, f16s_dgrad=f16s_dgrad)
+            if f16s:
+                st.note_f16s_backward(work, z.shape[0], z.shape[1])
             out, off = [], 0
             for k in st.names:
                 shape = _param_shape(net, k)
@@ -210,6 +256,17 @@ def render_train(rays: torch.Tensor, model: torch.nn.Module, opts, *, t_rand=Non
     if Nf > 0:
         out["rgb_f"], out["disp_f"] = rgb_f, disp_f
     return out
+
+
+def f16s_status(model: torch.nn.Module, reset: bool = True) -> Dict[str, float]:
+    """What the split-precision training steps of ``model`` saw since the last read (one device -> host copy): max |d_raw|, max |delta * s|
+    (how much of the f16 range the scaled backward chain used; >= 65504 means a conversion saturated and gradients were clipped), the number
+    of weights the split-precision packers could not represent, and ``saturated``.  The training path itself reads these on the first f16s
+    backward and every F16S_CHECK_EVERY-th after it, and raises / warns; this is the on-demand read."""
+    st = _states.get(model)
+    if st is None:
+        return {"max_abs_d_raw": 0.0, "max_abs_delta_scaled": 0.0, "weights_out_of_range": 0, "saturated": False}
+    return st.read_f16s(reset)
 
 
 def rank_seed(seed: int, rank: int) -> int:

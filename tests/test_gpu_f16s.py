@@ -374,6 +374,65 @@ def test_f16s_backward_gradient_range(gain, exact, n, S, lego_rays):
         assert top_scaled >= 65504.0, top_scaled                                 # the saturation is visible to the caller
 
 
+def test_training_path_notices_a_saturated_f16s_backward(lego_rays, monkeypatch):
+    """A 4000x amplification inside the backward chain, through the TRAINING path (render_train -> loss.backward()): the step reads the range words the
+    split-precision backward left behind on the first such backward (and every F16S_CHECK_EVERY-th after it) and raises; in "warn" mode it
+    warns and f16s_status() reports the numbers; a well-scaled network passes with the scaled chain inside the f16 range."""
+    import warnings
+    from types import SimpleNamespace
+    from nerf_pytorch_paeng_amd import train_path
+    from nerf_pytorch_paeng_amd._lib import MiNerfError
+    from nerf_pytorch_paeng_amd.model import NeRF
+    n, Sc, Nf = 128, 32, 32
+    rays = lego_rays[:n].contiguous()
+    opts = SimpleNamespace(near=2.0, far=6.0, N_samples_c=Sc, N_samples_f=Nf, perturb=1.0)
+    tgt = torch.rand(n, 3, generator=torch.Generator().manual_seed(2)).to(DEV)
+
+    def step(model):
+        model.zero_grad(set_to_none=True)
+        out = train_path.render_train(rays, model, opts, seed=3, f16s=True)
+        (torch.mean((out["rgb_c"] - tgt) ** 2) + torch.mean((out["rgb_f"] - tgt) ** 2)).backward()
+
+    def make(gain):
+        sd = synthetic.make_state_dict(9, 4, 256, skips=())
+        for pre in ("model_coarse.", "model_fine."):
+            # amplification in the BACKWARD chain's middle only: linear_feat / gain, linear_d's feature columns x gain -- the forward sees small
+            # features and ordinary activations either side (in range for the f16s forward), the backward sees delta_f = gain x (...)
+            sd[pre + "linear_feat.weight"] = (sd[pre + "linear_feat.weight"] / gain).astype(np.float32)
+            sd[pre + "linear_feat.bias"] = (sd[pre + "linear_feat.bias"] / gain).astype(np.float32)
+            w = sd[pre + "linear_d.weight"].copy()
+            w[:, :256] *= gain
+            sd[pre + "linear_d.weight"] = w.astype(np.float32)
+        m = NeRF(4, 256, 63, 27, skips=[]).to(DEV)
+        m.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+        return m
+
+    good = make(16.0)
+    step(good)
+    st = train_path.f16s_status(good)
+    assert not st["saturated"] and 128.0 <= st["max_abs_delta_scaled"] < 65504.0 and st["weights_out_of_range"] == 0, st
+    assert all(torch.isfinite(p.grad).all() for p in good.parameters())
+
+    bad = make(4000.0)
+    with pytest.raises((MiNerfError, RuntimeError), match="split-precision training step out of range"):
+        step(bad)
+    monkeypatch.setattr(train_path, "F16S_ON_SATURATION", "warn")
+    bad2 = make(4000.0)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        step(bad2)
+    assert any("out of range" in str(x.message) for x in w)
+    # the cadence: the next F16S_CHECK_EVERY - 2 backwards are not read, f16s_status reads on demand
+    monkeypatch.setattr(train_path, "F16S_CHECK_EVERY", 1000)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        step(bad2)
+    assert not w
+    st = train_path.f16s_status(bad2)
+    assert st["saturated"] and st["max_abs_delta_scaled"] >= 65504.0, st
+    assert not train_path.f16s_status(bad2)["saturated"]                         # read and reset
+
+
 def test_f16s_training_llff_and_two_slabs(monkeypatch):
     """The split-precision step through the NDC (llff) entry, with the batch cut into two autograd nodes (slab size lowered): losses and
     coarse-network gradients equal the fp32 path's to fp32 rounding; harness.train takes the mode as opts.precision."""

@@ -547,6 +547,35 @@ def test_post_process_is_differentiable_in_rgb():
         assert not NP.post_process(raw_d, z.to(DEV), rays[:, 3:].contiguous().to(DEV))[0].requires_grad
 
 
+def test_empty_batch_backward_is_zero_not_uninitialised_memory():
+    """An empty slab / an empty embedded batch: the library returns before any weight-gradient kernel runs, and ops.mlp_backward allocates
+    the flat gradient uninitialised -- so the library zero-fills it (autograd's answer for the gradient of nothing).  Poisoned buffers
+    through both entry points, and model(x[0:0]) under autograd."""
+    from nerf_pytorch_paeng_amd.model import NeRF
+    net = ops.make_net(4, 128, 1)
+    sd = synthetic.make_state_dict(5, 4, 128, skips=(1,))
+    packed = ops.pack_module(sd, "model_fine.", net).to(DEV)
+    packed_bwd = ops.pack_module(sd, "model_fine.", net, backward=True).to(DEV)
+    S = 24
+    rays, z, d_raw = torch.empty(0, 6, device=DEV), torch.empty(0, S, device=DEV), torch.empty(0, S, 4, device=DEV)
+    raw, stash = ops.mlp_rays_train(net, packed, rays, z)
+    assert raw.shape == (0, S, 4)
+    poison = torch.full((ops.param_count(net),), float("nan"), device=DEV)
+    grads, _ = ops.mlp_backward(net, packed, packed_bwd, rays, z, d_raw, stash, grads=poison)
+    assert grads.data_ptr() == poison.data_ptr() and torch.count_nonzero(poison).item() == 0
+    assert ops.mlp_backward(net, packed, packed_bwd, rays, z, d_raw, stash, stage=1)[0] is None      # deltas only: no gradient vector to mistake for one
+    x = torch.empty(0, 90, device=DEV)
+    out, st = ops.mlp_embedded_train(net, packed, x)
+    poison.fill_(float("nan"))
+    g2 = ops.mlp_embedded_backward(net, packed, packed_bwd, x, torch.empty(0, 4, device=DEV), st, grads=poison)
+    assert torch.count_nonzero(g2).item() == 0
+    model = NeRF(4, 128, 63, 27, skips=[1]).to(DEV)
+    y = model(x, True)
+    assert y.shape == (0, 4) and y.requires_grad
+    y.sum().backward()
+    assert all(p.grad is not None and torch.count_nonzero(p.grad).item() == 0 for p in model.model_fine.parameters())
+
+
 @pytest.mark.parametrize("D,W,skip,n", [(8, 256, 4, 777), (4, 128, 1, 64), (4, 128, 1, 33)])
 def test_model_forward_is_differentiable_like_the_reference_module(D, W, skip, n):
     """model(embedded, is_fine) with gradients enabled -- the call the reference's own render_rays makes (nerf_process.py:190-192):
@@ -619,7 +648,9 @@ def test_F11_backward_matches_the_reference_training_step(golden, tag, f16s):
         e_ref = rel_err(want, psd[k].grad)                 # the reference's fp32 noise on this tensor
         e = float((p.grad.cpu().double() - psd[k].grad.double()).abs().max()) / float(want.abs().max())
         worst, worst_ref = max(worst, e), max(worst_ref, e_ref)
-        assert e <= 3.0 * e_ref + 2e-5, (k, e, e_ref)
+        # ... capped in absolute terms from what is observed (fp32 forward 3.7e-5 on the cancelling trunk tensors, split-precision forward
+        # 5.8e-6): a tenfold regression fails whatever the reference's own noise on the tensor
+        assert e <= min(3.0 * e_ref + 2e-5, 2e-5 if f16s else 1.5e-4), (k, e, e_ref)
         assert rel_err(p.grad, want) <= 4.0 * e_ref + 2e-5, (k, rel_err(p.grad, want), e_ref)
         n += 1
     assert n == (48 if D == 8 else 32)
