@@ -274,22 +274,19 @@ int mi_nerf_mlp_embedded_backward(const mi_nerf_net* net, const void* packed_dev
                                   int64_t n, const float* d_out_dev, const void* stash_dev, void* work_dev, size_t work_bytes,
                                   float* grads_dev, void* stream);
 
-/* One weight-gradient product of the backward pass on its own: out[M, ldo] = delta[P, ldd]^T x[P, ldx] (first M / N columns),
- * bias[M] = column sums of delta (may be NULL) -- what autograd computes for one nn.Linear (model/NeRF.py:24-30).  The wide
- * operands of the network's own products (an operand wider than 64 columns) must be 16-byte aligned with pitches of 4 floats;
- * no operand is read outside its P rows (the load pipelines run ahead of the data through range-checked buffer loads: requests
- * past row P - 1 return zeros without touching memory).  scratch: mi_nerf_wgrad_scratch_bytes() bytes.
- * iters launches back to back; avg_ms_out (may be NULL) = their average device time by hipEvents on `stream`
- * (bench.py's roofline leg for the training kernels; synchronises the stream when given). */
+/* Weight-gradient products of the backward pass on their own: n (1..12) products over the SAME P points,
+ * out[b][M_b, ldo_b] = delta[b][P, ldd_b]^T x[b][P, ldx_b] (first M_b / N_b columns), bias[b][M_b] = column sums of delta[b] -- what
+ * autograd computes for one nn.Linear each (model/NeRF.py:24-30).  Products with both sides wider than 64 columns (at most 256) share
+ * ONE launch -- the form the backward pass itself uses for the nine 256 x 256 products of an 8 x 256 network: the CUs are shared out
+ * between them, so each is cut into (CUs / n) point slices and writes / reduces 1 / n of the partial sums a launch of its own does
+ * (nine 256 x 256 products over 786 432 points: 0.925 of the fp32 MFMA peak; n = 1: 0.78, which is why there is no single-product
+ * entry any more -- round 4).  A product with a side of at most 64 columns (gamma(x), gamma(d), the heads) runs in a launch of its
+ * own behind the wide batch.  Operands wider than 64 columns must be 16-byte aligned with pitches of 4 floats; no operand is read outside
+ * its P rows (the load pipelines run ahead of the data through range-checked buffer loads: requests past row P - 1 return zeros without
+ * touching memory).  Arrays of n HOST entries (device pointers, pitches, sizes); bias_dev may be NULL, or hold NULL entries.
+ * scratch: mi_nerf_wgrad_scratch_bytes() bytes.  iters launches back to back; avg_ms_out (may be NULL) = their average device time by
+ * hipEvents on `stream` (bench.py's roofline leg for the training kernels; synchronises the stream when given). */
 size_t mi_nerf_wgrad_scratch_bytes(void);
-int mi_nerf_wgrad_product(const float* delta_dev, int ldd, int M, const float* x_dev, int ldx, int N, int64_t P, float* out_dev,
-                          int ldo, float* bias_dev, void* scratch_dev, size_t scratch_bytes, int iters, float* avg_ms_out,
-                          void* stream);
-/* n (1..12) such products over the SAME P points in ONE launch, both sides wider than 64 columns (at most 256): the form the
- * backward pass itself uses for the nine 256 x 256 products of an 8 x 256 network.  The CUs are shared out between the products,
- * so each is cut into (CUs / n) point slices and writes / reduces 1 / n of the partial sums a stand-alone launch does (a lone
- * 256 x 256 product over 786 432 points: 0.74 of the fp32 MFMA peak; nine in one launch: 0.91).  Arrays of n HOST entries
- * (device pointers, pitches, sizes); bias_dev may be NULL, or hold NULL entries. */
 int mi_nerf_wgrad_products(int n, const float* const* delta_dev, const int* ldd, const int* M, const float* const* x_dev, const int* ldx,
                            const int* N, int64_t P, float* const* out_dev, const int* ldo, float* const* bias_dev, void* scratch_dev,
                            size_t scratch_bytes, int iters, float* avg_ms_out, void* stream);

@@ -105,7 +105,6 @@ SIGNATURES = {
     "mi_nerf_mlp_embedded_train": (_I, [_NETP, _P, _P, _I64, _P, _P, _SZ, _P]),
     "mi_nerf_mlp_embedded_backward": (_I, [_NETP, _P, _P, _P, _I64, _P, _P, _P, _SZ, _P, _P]),
     "mi_nerf_wgrad_scratch_bytes": (_SZ, []),
-    "mi_nerf_wgrad_product": (_I, [_P, _I, _I, _P, _I, _I, _I64, _P, _I, _P, _P, _SZ, _I, C.POINTER(_F), _P]),
     "mi_nerf_wgrad_products": (_I, [_I, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _SZ, _I, C.POINTER(_F), _P]),
     "mi_nerf_wgrad_products_f16s": (_I, [_I, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _SZ, _I, C.POINTER(_F), _P]),
     "mi_nerf_image_metrics": (_I, [_P, _P, _I64, _P, _P, _SZ, _P]),

@@ -81,7 +81,6 @@ int mlp_backward_fp32(const mi_nerf_net*, const void*, const void*, const float*
 int mlp_embedded_fp32_stash(const mi_nerf_net*, const void*, const float*, int64_t, float*, float*, float*, float*, unsigned*, unsigned*,
                             hipStream_t);
 int train_layout(const mi_nerf_net*, int64_t, int, mi_nerf_train_layout*);
-int wgrad_product(const float*, int, int, const float*, int, int, int64_t, float*, int, float*, void*, size_t, hipStream_t);
 size_t wgrad_scratch_bytes();
 int pack_apply(const int32_t*, const float*, size_t, void*, hipStream_t);
 int pack_bwd_fp32(const mi_nerf_net*, const mi_nerf_params*, void*, size_t);
@@ -380,10 +379,10 @@ int mi_nerf_mlp_embedded_backward(const mi_nerf_net* net, const void* packed, co
                                   const void* stash, void* work, size_t work_bytes, float* grads, void* st) {
     if (int rc = check_net_basic(net)) return rc;
     MN_CHECK_ARG(n >= 0, "bad n=%lld", (long long)n);
-    if (n == 0) return MI_NERF_OK;
-    MN_CHECK_ARG(x != nullptr, "NULL device pointer");
+    MN_CHECK_ARG(x != nullptr || n == 0, "NULL device pointer");          // n == 0: mlp_backward_fp32 zero-fills grads (the gradient of nothing)
+    static const float no_rows = 0.0f;                                     // never dereferenced: a non-NULL x selects the embedded mode
     return mlp_backward_fp32(net, packed, packed_bwd, nullptr, nullptr, (n + 31) / 32, 32, d_out, stash, work, work_bytes, grads, 0, (hipStream_t)st,
-                             x, n, 0);
+                             x ? x : &no_rows, n, 0);
 }
 
 int mi_nerf_image_metrics(const float* pred, const float* target, int64_t n, float* out2, void* scratch, size_t scratch_bytes, void* st) {
@@ -502,11 +501,6 @@ static int timed_launches(int iters, float* avg_ms, hipStream_t st, F body) {
         *avg_ms = ms / (float)iters;
     }
     return rc;
-}
-int mi_nerf_wgrad_product(const float* delta, int ldd, int M, const float* x, int ldx, int N, int64_t P, float* out, int ldo, float* bias,
-                          void* scratch, size_t scratch_bytes, int iters, float* avg_ms, void* stream) {
-    hipStream_t st = (hipStream_t)stream;
-    return timed_launches(iters, avg_ms, st, [&] { return wgrad_product(delta, ldd, M, x, ldx, N, P, out, ldo, bias, scratch, scratch_bytes, st); });
 }
 int mi_nerf_wgrad_products(int n, const float* const* delta, const int* ldd, const int* M, const float* const* x, const int* ldx, const int* N,
                            int64_t P, float* const* out, const int* ldo, float* const* bias, void* scratch, size_t scratch_bytes, int iters,

@@ -19,11 +19,12 @@
 //         [hi.hi p0] [hi.hi p1] [hi.lo p0] [hi.lo p1] [lo.hi p0] [lo.hi p1]
 //     the first two gaps carry the ring work (one A read each, the slot's DMAs), the other four the packing;
 //   * packing a pair of accumulator elements (12 VALU): y = fma(lo, 2^-11, hi); Y = fma(hi, 2^11, lo) (= 2^11 y); hi_pk =
-//     v_cvt_pk_f16_f32(y0, y1) [v_pk_max_f16 for ReLU, Y = max(Y, 0)]; lo halves by v_fma_mixlo/hi_f16(hi_half, -2^11, Y): the
+//     v_cvt_pk_f16_f32(y0, y1) [v_pk_maximum3_f16 for ReLU, Y = maximum(Y, 0): NaN-propagating]; lo halves by v_fma_mixlo/hi_f16(hi_half, -2^11, Y): the
 //     residual (y - hi) 2^11 computed exactly and rounded once; two v_accvgpr_write;
 //   * gamma(x) is evaluated in full precision per channel (Cody-Waite + Cephes like the fp32 kernel, libm beyond 4e6 rad), not by
 //     angle doubling: this variant's contract is fp32-grade output.
-// Ranges: |weights| and |activations| must stay below the f16 maximum (65 504); the packer refuses larger weights.
+// Ranges: |weights| and |activations| must stay below the f16 maximum (65 504).  The packer refuses larger weights; an activation beyond it
+// comes out as NaN in every output that depends on it, never as a finite value (NaN-propagating ReLU: mlp_f16s_core.h "RANGE CONTRACT").
 
 #include "mlp_f16s_core.h"
 

@@ -168,16 +168,22 @@ __device__ __forceinline__ void mfma_a(f32x4& acc, const u32x4b& afrag, const u3
 
 // ---- packing: a pair of accumulator elements (registers 2e, 2e+1 of a finished tile) -> one dword of the hi fragment, one of the lo
 // fragment.  Six stages of two instructions (one stage per MFMA gap), or as one block where a job has more work than gaps.
+// RANGE CONTRACT (round 4): an activation y >= 65520 converts to hi = +inf, lo = -inf; every unit of the next layer then accumulates
+// inf - inf = NaN -- and the ReLU here is gfx950's NaN-PROPAGATING maximum (v_pk_maximum3_f16 / v_maximum3_f32, IEEE 754-2019), not
+// v_pk_max_f16 / v_max_f32, which return the other operand for a NaN and turned the whole layer into plausible zeros.  So an activation
+// beyond the f16 range yields NaN in every output that depends on it (all four for a trunk unit; the three colours for a feature / direction
+// unit), never a finite value; y <= -65520 in front of a ReLU is exact (hi = lo = 0, what fp32 gives).  tests/test_gpu_f16s.py
+// test_f16s_forward_out_of_range_is_never_a_finite_colour; same instruction count as before.
 struct PairTmp { float y0, y1, Y0, Y1; unsigned hi, lo; };
 template <bool RELU, int RH, int RL, int STAGE>
 __device__ __forceinline__ void pack_stage(const float h0, const float h1, const float l0, const float l1, PairTmp& t, float dn, float up, float nup) {
     if constexpr (STAGE == 0) asm volatile("v_fma_f32 %0, %2, %6, %3\n\tv_fma_f32 %1, %4, %6, %5" : "=&v"(t.y0), "=&v"(t.y1) : "v"(l0), "v"(h0), "v"(l1), "v"(h1), "s"(dn));
     else if constexpr (STAGE == 1) asm volatile("v_fma_f32 %0, %2, %6, %3\n\tv_fma_f32 %1, %4, %6, %5" : "=&v"(t.Y0), "=&v"(t.Y1) : "v"(h0), "v"(l0), "v"(h1), "v"(l1), "s"(up));
     else if constexpr (STAGE == 2) {
-        if (RELU) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2\n\tv_pk_max_f16 %0, %0, 0" : "=&v"(t.hi) : "v"(t.y0), "v"(t.y1));
+        if (RELU) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2\n\tv_pk_maximum3_f16 %0, %0, 0, 0" : "=&v"(t.hi) : "v"(t.y0), "v"(t.y1));
         else asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=&v"(t.hi) : "v"(t.y0), "v"(t.y1));
     } else if constexpr (STAGE == 3) {
-        if (RELU) asm volatile("v_max_f32 %0, %0, 0\n\tv_max_f32 %1, %1, 0" : "+v"(t.Y0), "+v"(t.Y1));
+        if (RELU) asm volatile("v_maximum3_f32 %0, %0, 0, 0\n\tv_maximum3_f32 %1, %1, 0, 0" : "+v"(t.Y0), "+v"(t.Y1));
     } else if constexpr (STAGE == 4) {
         // lo halves: f16((y - hi) * 2^11) = f16(fma(hi, -2^11, Y)): the residual is exact, rounded once.  mixlo writes bits 15:0 of the
         // destination, mixhi bits 31:16 (each keeps the other half): the pair lands packed.

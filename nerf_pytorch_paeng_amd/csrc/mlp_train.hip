@@ -915,21 +915,25 @@ static int run_wgrad(const float* dlt, int ldd, int M, const float* x, int ldx, 
 
 size_t wgrad_scratch_bytes() { return WGRAD_PARTIAL_FLOATS * 4 + 256; }      // partials + the max|delta| word of the split-precision entry
 
-// n (<= 12) wide products over the SAME P points in one launch -- how the backward pass itself runs the nine 256 x 256 products of
-// a network (run_wgrad_batch): the CUs are shared out between the products, so a product is cut into num_cus / n point slices
-// and writes / reduces 1 / n of the partials a stand-alone launch does.
-// f16s: the products in split precision (wgrad_f16s_kernel); the gradient operands are scaled from the largest |delta| entry of the batch,
-// found on the device first (one pass over the deltas: the training step takes it from d_raw instead)
+// n (<= 12) products over the SAME P points -- how the backward pass itself runs the nine 256 x 256 products of a network
+// (run_wgrad_batch): the WIDE ones (both sides wider than 64 columns) share ONE launch, the CUs shared out between them, so a product is
+// cut into num_cus / n point slices and writes / reduces 1 / n of the partials a launch of its own does; a product with a narrow side
+// (gamma(x), gamma(d), the heads) goes through wgrad_narrow_kernel in a launch of its own, in list order behind the wide batch.
+// f16s: the products in split precision (wgrad_f16s_kernel; wide products only); the gradient operands are scaled from the largest |delta|
+// entry of the batch, found on the device first (one pass over the deltas: the training step takes it from d_raw instead)
 int wgrad_products(int n, const float* const* dlt, const int* ldd, const int* M, const float* const* x, const int* ldx, const int* N, int64_t P,
                    float* const* out, const int* ldo, float* const* bias, void* scratch, size_t scratch_bytes, hipStream_t st, bool f16s) {
     MN_CHECK_ARG(n >= 1 && n <= WG_MAXB, "between 1 and %d products per launch (got %d)", WG_MAXB, n);
     MN_CHECK_ARG(P >= 1 && dlt && ldd && M && x && ldx && N && out && ldo && scratch, "bad sizes / NULL pointer");
     MN_CHECK_ARG(scratch_bytes >= wgrad_scratch_bytes(), "scratch too small: %zu < %zu", scratch_bytes, wgrad_scratch_bytes());
     WideProduct pr[WG_MAXB];
+    int n_wide = 0;
     for (int b = 0; b < n; ++b) {
-        MN_CHECK_ARG(dlt[b] && x[b] && out[b] && M[b] > 64 && N[b] > 64 && ldd[b] >= M[b] && ldx[b] >= N[b] && ldo[b] >= N[b],
-                     "product %d: the batched entry takes wide products (more than 64 columns on both sides), M=%d N=%d", b, M[b], N[b]);
-        pr[b] = WideProduct{dlt[b], ldd[b], M[b], x[b], ldx[b], N[b], out[b], ldo[b], bias ? bias[b] : nullptr};
+        MN_CHECK_ARG(dlt[b] && x[b] && out[b] && M[b] >= 1 && N[b] >= 1 && ldd[b] >= M[b] && ldx[b] >= N[b] && ldo[b] >= N[b],
+                     "product %d: bad sizes M=%d N=%d (pitches %d / %d / %d) or NULL pointer", b, M[b], N[b], ldd[b], ldx[b], ldo[b]);
+        const bool wide = M[b] > 64 && N[b] > 64;
+        MN_CHECK_ARG(wide || !f16s, "product %d: the split-precision entry takes wide products (more than 64 columns on both sides), M=%d N=%d", b, M[b], N[b]);
+        if (wide) pr[n_wide++] = WideProduct{dlt[b], ldd[b], M[b], x[b], ldx[b], N[b], out[b], ldo[b], bias ? bias[b] : nullptr};
     }
     unsigned* absmax = nullptr;
     if (f16s) {
@@ -941,16 +945,12 @@ int wgrad_products(int n, const float* const* dlt, const int* ldd, const int* M,
         }
         MN_LAUNCH_CHECK("absmax_kernel");
     }
-    return run_wgrad_batch(pr, n, P, (float*)scratch, st, absmax);
-}
-
-// stand-alone product dW = delta^T x input (+ column sums of delta) for tests and the bench's roofline leg
-int wgrad_product(const float* dlt, int ldd, int M, const float* x, int ldx, int N, int64_t P, float* out, int ldo, float* bias, void* scratch,
-                  size_t scratch_bytes, hipStream_t st) {
-    MN_CHECK_ARG(P >= 1 && M >= 1 && N >= 1 && ldd >= M && ldx >= N && ldo >= N, "bad sizes P=%lld M=%d N=%d", (long long)P, M, N);
-    MN_CHECK_ARG(dlt && x && out && scratch, "NULL device pointer");
-    MN_CHECK_ARG(scratch_bytes >= WGRAD_PARTIAL_FLOATS * 4, "scratch too small: %zu < %zu", scratch_bytes, WGRAD_PARTIAL_FLOATS * 4);
-    return run_wgrad(dlt, ldd, M, x, ldx, N, P, out, ldo, bias, (float*)scratch, st);
+    if (n_wide)
+        if (int rc = run_wgrad_batch(pr, n_wide, P, (float*)scratch, st, absmax)) return rc;
+    for (int b = 0; b < n; ++b)                                  // the same scratch, in stream order
+        if (!(M[b] > 64 && N[b] > 64))
+            if (int rc = run_wgrad(dlt[b], ldd[b], M[b], x[b], ldx[b], N[b], P, out[b], ldo[b], bias ? bias[b] : nullptr, (float*)scratch, st)) return rc;
+    return MI_NERF_OK;
 }
 
 template <int W>

@@ -204,6 +204,18 @@ def _precision(opts) -> Dict[str, bool]:
     return {"bf16": mode == "bf16", "f16s": mode == "f16s"}
 
 
+def _frozen(model, opts):
+    """The model packed ONCE for a whole test() / render() call (the weights do not change inside it; packed_for() on an nn.Module re-packs
+    per call otherwise).  Split precision: the blobs are built here and the device packer's out-of-range count is read once -- a checkpoint
+    with a weight beyond the f16 range raises instead of rendering from a clipped network."""
+    from .weights import packed_for
+    packed = packed_for(model)
+    if _precision(opts)["f16s"]:
+        packed.f16s()
+        packed.check_f16s_range()
+    return packed
+
+
 def _render_pose(model, posenc, K, pose, hw, opts):
     img_h, img_w = hw
     rays_o, rays_d = make_o_d(img_w, img_h, K, pose[:3, :4])
@@ -228,9 +240,10 @@ def test(idx, i_test, posenc, model, test_imgs, gt_intrinsic, gt_extrinsic, hw, 
     psnrs: List[float] = []
     frames = []
     with torch.no_grad():
+        frozen = _frozen(model, opts)
         for i, pose in enumerate(gt_extrinsic):
             pose = as_f32_dev(pose, dev)
-            pred_rgb, pred_disp = _render_pose(model, posenc, gt_intrinsic, pose, hw, opts)
+            pred_rgb, pred_disp = _render_pose(frozen, posenc, gt_intrinsic, pose, hw, opts)
             target = as_f32_dev(test_imgs[i], pred_rgb.device).reshape(-1, 3)             # test.py:63
             m = ops.image_metrics(pred_rgb, target)                                       # img2mse, mse2psnr: test.py:65-67
             rgb8 = ops.to8b(pred_rgb).reshape(img_h, img_w, 3)                            # test.py:55
@@ -281,8 +294,9 @@ def render(idx, posenc, model, gt_intrinsic, render_pose, hw, opts, *, log_dir: 
     rgbs = torch.empty(n, img_h, img_w, 3, dtype=torch.uint8, device=dev)
     disps = torch.empty(n, img_h, img_w, dtype=torch.uint8, device=dev)
     with torch.no_grad():
+        frozen = _frozen(model, opts)
         for i in range(n):
-            rgb, disp = _render_pose(model, posenc, gt_intrinsic, poses[i], hw, opts)
+            rgb, disp = _render_pose(frozen, posenc, gt_intrinsic, poses[i], hw, opts)
             rgbs[i] = ops.to8b(rgb).reshape(img_h, img_w, 3)                              # to8b(rgbs), test.py:167
             disps[i] = ops.to8b(disp, ops.nanmax(disp)).reshape(img_h, img_w)             # disp / nanmax, test.py:156,168
     rgbs_np, disps_np = rgbs.cpu().numpy(), disps.cpu().numpy()                           # one copy for the whole clip

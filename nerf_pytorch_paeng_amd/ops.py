@@ -459,27 +459,17 @@ def mlp_embedded_backward(net: Net, packed: torch.Tensor, packed_bwd: torch.Tens
 
 
 def wgrad_product(delta: torch.Tensor, M: int, x: torch.Tensor, N: int, P: int, want_bias: bool = True, iters: int = 1, timed: bool = False):
-    """out[M,N] = delta[:P,:M]^T x[:P,:N] (+ bias[M] = column sums of delta) with the backward pass's own kernels.
-    ``delta`` / ``x`` are 2-D row-major with at least P rows (nothing past row P - 1 is read).  Returns
-    (out, bias, avg_ms) -- avg_ms only when ``timed``."""
-    dev = delta.device
-    if delta.dim() != 2 or x.dim() != 2 or delta.shape[0] < P or x.shape[0] < P or delta.shape[1] < M or x.shape[1] < N:
-        raise MiNerfError(f"operands {tuple(delta.shape)} / {tuple(x.shape)} too small for P={P}, M={M}, N={N}")
-    out = torch.empty(M, N, dtype=torch.float32, device=dev)
-    bias = torch.empty(M, dtype=torch.float32, device=dev) if want_bias else None
-    scratch = torch.empty(int(lib().mi_nerf_wgrad_scratch_bytes()), dtype=torch.uint8, device=dev)
-    ms = C.c_float(0.0)
-    with _guard(dev):
-        check(lib().mi_nerf_wgrad_product(dev_ptr(delta, "delta"), delta.stride(0), int(M), dev_ptr(x, "x"), x.stride(0), int(N), int(P), dev_ptr(out),
-                                          N, dev_ptr(bias), dev_ptr(scratch, "scratch", torch.uint8, 16), scratch.numel(), int(iters),
-                                          C.byref(ms) if timed else None, stream_ptr(dev)), "mi_nerf_wgrad_product")
-    return out, bias, (float(ms.value) if timed else None)
+    """out[M,N] = delta[:P,:M]^T x[:P,:N] (+ bias[M] = column sums of delta): ``wgrad_products`` with one product (the C ABI has no
+    single-product entry since round 4).  Returns (out, bias, avg_ms) -- avg_ms only when ``timed``."""
+    outs, biases, ms = wgrad_products([delta], [x], P, [int(M)], [int(N)], want_bias, iters, timed)
+    return outs[0], (biases[0] if want_bias else None), ms
 
 
 def wgrad_products(deltas: Sequence[torch.Tensor], xs: Sequence[torch.Tensor], P: int, Ms: Optional[Sequence[int]] = None,
                    Ns: Optional[Sequence[int]] = None, want_bias: bool = True, iters: int = 1, timed: bool = False, f16s: bool = False):
-    """Several wide products over the same P points in ONE launch (mi_nerf_wgrad_products): out[b] = deltas[b][:P, :M_b]^T xs[b][:P, :N_b]
-    (+ bias[b] = column sums of deltas[b]).  This is how the backward pass runs a network's 256 x 256 products.  ``f16s``: in split
+    """Several products over the same P points (mi_nerf_wgrad_products): out[b] = deltas[b][:P, :M_b]^T xs[b][:P, :N_b]
+    (+ bias[b] = column sums of deltas[b]).  The wide ones (both sides wider than 64 columns) share ONE launch -- how the backward pass
+    runs a network's 256 x 256 products -- a product with a narrow side runs in a launch of its own behind them.  ``f16s``: in split
     precision (mi_nerf_wgrad_products_f16s; fp32-grade results, bound by the operands' HBM reads).  Returns (outs, biases, avg_ms)."""
     n = len(deltas)
     if n == 0 or len(xs) != n:

@@ -101,25 +101,33 @@ class PackedNeRF:
         return self._bf16
 
     def f16s(self) -> Tuple[torch.Tensor, torch.Tensor]:
-        """Blobs of the split-precision variant (weights as f16 hi + lo pairs), packed lazily on the host: from the kept state dict, or
-        -- a PackedNeRF made from an nn.Module -- from its flat parameter vectors (one device -> host copy per packed_for() call: pass
-        a PackedNeRF to render many batches from frozen weights)."""
+        """Blobs of the split-precision variant (weights as f16 hi + lo pairs), packed lazily: on the device from the flat parameter
+        vectors when this PackedNeRF came from an nn.Module (like bf16(): packed_for() makes a new one per call, so a host round trip
+        here would be a synchronisation per render call), on the host from the kept state dict otherwise (once; the host packer refuses
+        weights beyond the f16 range outright).  The device packer cannot refuse: it counts such weights into ``f16s_out_of_range``
+        (a device int32), which ``check_f16s_range()`` reads."""
         if self._f16s is None:
-            sd = self._sd
-            if sd is None:
-                if self._flat is None:
+            if self._flat is not None:
+                key = (tuple(getattr(self.net, f) for f, _ in Net._fields_), str(self.device))
+                if key not in _maps_f16s:
+                    _maps_f16s[key] = ops.pack_map_f16s(self.net).to(self.device)
+                self.f16s_out_of_range = torch.zeros(1, dtype=torch.int32, device=self.device)
+                self._f16s = tuple(ops.pack_apply_f16s(self.net, _maps_f16s[key], flat, self.f16s_out_of_range) for flat in self._flat)
+            else:
+                if self._sd is None:
                     raise MiNerfError("f16-split packing needs the state dict (keep_state=True)")
-                sd = {}
-                for prefix, flat in zip(("model_coarse.", "model_fine."), self._flat):
-                    host, off = flat.detach().cpu().numpy(), 0
-                    for name in ops.param_names(self.net):
-                        shape = _param_shape(self.net, name)
-                        cnt = int(np.prod(shape))
-                        sd[prefix + name] = host[off:off + cnt].reshape(shape)
-                        off += cnt
-            self._f16s = (ops.pack_module(sd, "model_coarse.", self.net, f16s=True).to(self.device),
-                          ops.pack_module(sd, "model_fine.", self.net, f16s=True).to(self.device))
+                self._f16s = (ops.pack_module(self._sd, "model_coarse.", self.net, f16s=True).to(self.device),
+                              ops.pack_module(self._sd, "model_fine.", self.net, f16s=True).to(self.device))
         return self._f16s
+
+    def check_f16s_range(self) -> int:
+        """Weights the device-side split-precision packer could not represent (NaN or beyond the f16 range) -- one device -> host read;
+        raises when there are any.  The eval harness calls it once per test() / render() call, not per frame."""
+        cnt = getattr(self, "f16s_out_of_range", None)
+        n = 0 if cnt is None else int(cnt.item())
+        if n:
+            raise MiNerfError(f"{n} weight(s) are NaN or beyond the f16 range (65504): the split-precision variant cannot carry this network; use precision 'fp32'")
+        return n
 
     def blob(self, is_fine: bool) -> torch.Tensor:
         return self.fine if is_fine else self.coarse
@@ -151,6 +159,7 @@ def packed_for(model, device=None) -> PackedNeRF:
 # gather maps per network shape (built once by the host packer, kept on the device)
 _maps: Dict[tuple, torch.Tensor] = {}
 _maps_bf16: Dict[tuple, torch.Tensor] = {}
+_maps_f16s: Dict[tuple, torch.Tensor] = {}
 
 
 def _pack_module_on_device(model: torch.nn.Module, device: torch.device) -> PackedNeRF:

@@ -74,6 +74,84 @@ def test_f16s_mlp_vs_oracles(D, skip, L_x, L_d, n, S, lego_rays):
     assert e64 <= 4.0 * max(e_ref, e_k32) + 1e-6, (e64, e_ref, e_k32)
 
 
+@pytest.mark.parametrize("stash", [False, True])
+def test_f16s_forward_out_of_range_is_never_a_finite_colour(stash, lego_rays):
+    """RANGE CONTRACT of the split-precision forward (mlp_f16s_core.h), both instantiations (inference, training forward with stash): an
+    activation at or beyond 65 520 -- here one unit's bias -- comes out as NaN in EVERY output that depends on it, never as a finite value:
+      * a trunk unit (layer 3 of 8)       -> all four raw outputs of every point are NaN
+      * the LAST trunk unit layer         -> same (density reads it directly)
+      * a linear_feat unit (no ReLU)      -> the three colours are NaN, the density (which does not depend on it) is finite and right
+      * a linear_d unit (ReLU)            -> the three colours are NaN
+    y <= -65 520 in front of a ReLU is exact (the unit is off, as in fp32), and 65 000 stays in range: both equal the fp32 kernel.
+    The fp32 kernel itself is finite on all of these networks.  (Until round 4 the ReLU was v_pk_max_f16 / v_max_f32, which return the
+    OTHER operand for a NaN: the layer behind an overflow came out as zeros and the network as plausible finite colours.)"""
+    n, S, D = 40, 64, 8
+    rays = lego_rays[:n].contiguous()
+    z = torch.sort(T(R.counter_uniform(5, 0, 0, n, S)) * 4 + 2, -1)[0].to(DEV)
+
+    def run(sd):
+        packed = weights.PackedNeRF.from_state_dict(sd, DEV)
+        blob = packed.f16s()[1]
+        if stash:
+            got = ops.mlp_rays_train(packed.net, blob, rays, z, f16s=True)[0]
+        else:
+            got = ops.mlp_rays(packed.net, blob, rays, z, f16s=True)
+        return got.reshape(-1, 4), ops.mlp_rays(packed.net, packed.fine, rays, z).reshape(-1, 4)
+
+    def with_bias(name, unit, value):
+        sd = synthetic.make_state_dict(23, D, 256)
+        b = sd["model_fine." + name].copy()
+        b[unit] = value
+        sd["model_fine." + name] = b
+        return sd
+
+    base16, base32 = run(synthetic.make_state_dict(23, D, 256))
+    assert torch.isfinite(base16).all() and float((base16 - base32).abs().max()) < 1e-4
+    for name, unit in (("linear_x.3.bias", 7), ("linear_x.7.bias", 200), ("linear_x.0.bias", 0)):
+        got, ref = run(with_bias(name, unit, 70000.0))
+        assert torch.isfinite(ref).all()                                        # fp32 carries it
+        assert torch.isnan(got).all(), (name, int(torch.isfinite(got).sum()))   # every output of every point
+    got, ref = run(with_bias("linear_feat.bias", 11, 70000.0))
+    assert torch.isnan(got[:, :3]).all() and torch.isfinite(got[:, 3]).all()
+    assert float((got[:, 3] - ref[:, 3]).abs().max()) <= 1e-4 * max(1.0, float(ref[:, 3].abs().max()))
+    got, ref = run(with_bias("linear_d.bias", 5, 70000.0))
+    assert torch.isnan(got[:, :3]).all() and torch.isfinite(got[:, 3]).all()
+    # negative overflow in front of a ReLU: the unit is off, exactly as in fp32; just inside the range: ordinary accuracy
+    for value in (-70000.0, -1e9, 65000.0):
+        got, ref = run(with_bias("linear_x.3.bias", 7, value))
+        assert torch.isfinite(got).all(), value
+        assert float((got - ref).abs().max()) <= 2e-4 * max(1.0, float(ref.abs().max())), (value, float((got - ref).abs().max()))
+
+
+def test_module_source_f16s_blobs_are_packed_on_the_device(lego_rays):
+    """packed_for(nn.Module).f16s() builds the split-precision blobs on the device from the flat parameter vectors (no host round trip per
+    render call): bit-identical to the host packer's blobs; a weight beyond the f16 range, which the host packer refuses, is COUNTED by the
+    device packer and raised by check_f16s_range() -- the eval harness (opts.precision = "f16s") calls it once per test() / render()."""
+    from nerf_pytorch_paeng_amd import harness
+    from nerf_pytorch_paeng_amd.model import NeRF, get_positional_encoder
+    from nerf_pytorch_paeng_amd.weights import packed_for
+    sd = synthetic.make_state_dict(4, 8, 256)
+    model = NeRF(8, 256, 63, 27).to(DEV)
+    model.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+    dev_blobs = packed_for(model)
+    got = dev_blobs.f16s()
+    want = weights.PackedNeRF.from_state_dict(sd, DEV).f16s()
+    assert all(torch.equal(a, b) for a, b in zip(got, want))
+    assert dev_blobs.check_f16s_range() == 0
+    with torch.no_grad():
+        model.model_fine.linear_x[2].weight[3, 5] = 1.0e6
+    bad = packed_for(model)
+    bad.f16s()
+    with pytest.raises(MiNerfError, match="beyond the f16 range"):
+        bad.check_f16s_range()
+    K, H, W = synthetic.lego_camera()
+    opts = make_opts(precision="f16s", exp_name="x")
+    pose = torch.as_tensor(synthetic.pose_spherical(0.0, -30.0, 4.0), dtype=torch.float32)
+    posenc = get_positional_encoder(10), get_positional_encoder(4)
+    with pytest.raises(MiNerfError, match="beyond the f16 range"):
+        harness.test(0, [0], posenc, model, torch.zeros(1, 8, 8, 3), K, pose[None], (8, 8), opts)
+
+
 def test_f16s_config2_all_rays_vs_oracle(packed_big, lego_rays):
     """BASELINE config #2 at full size through the split-precision variant, EVERY ray against the CPU oracle, to the bars the fp32
     path is held to (test_config2_all_rays_vs_oracle): coarse colours and disparities directly; fine outputs with the depths pinned to
