@@ -578,7 +578,7 @@ def worker(args) -> None:
                                           "the three fp32-MFMA kernels (same stash, deltas and gradient layout; narrow products, compositing and Adam unchanged); "
                                           "gradients within the fp32 path's bars of an fp64 evaluation (tests/test_gpu_train.py F11, f16s case)"}
         # roofline leg of the training kernels' GEMM: the 256x256 weight-gradient products over the fine net's 786 432 points, as the
-        # backward pass runs them (nine in one launch: mi_nerf_wgrad_products), and one product launched on its own
+        # backward pass runs them (nine in one launch: mi_nerf_wgrad_products), and the same entry with one product
         n_pts = N_RAYS * (SC + NF)
         dlt = torch.randn(n_pts + 64, 256, device=dev)
         xin = torch.randn(n_pts + 64, 256, device=dev)
@@ -589,7 +589,7 @@ def worker(args) -> None:
         _, _, wg9_ms = ops.wgrad_products([dlt] * 9, [xin] * 9, n_pts, iters=5, timed=True)
         wg9_tf = 9 * 2.0 * 256 * 256 * n_pts / (wg9_ms * 1e-3) / 1e12
         train["wgrad_256x256"] = {"ms": round(wg_ms, 4), "achieved_TFLOPs": round(wg_tf, 1), "frac_of_f32_mfma_peak": round(wg_tf / PEAK_F32_MFMA_TFLOPS, 4),
-                                  "what": "ONE product on its own (mi_nerf_wgrad_product): wgrad_big_kernel over 256 point slices + reduce, hipEvents on the launch stream"}
+                                  "what": "ONE product in a launch of its own (mi_nerf_wgrad_products, n = 1: wgrad_big_kernel over 256 point slices + reduce; hipEvents on the launch stream) -- nothing on the path runs one alone, and the C ABI has no single-product entry since round 4"}
         if not args.no_f16s_leg:                                         # the same nine products in split precision: bound by their HBM reads
             ops.wgrad_products([dlt] * 9, [xin] * 9, n_pts, iters=1, f16s=True)
             _, _, wgs_ms = ops.wgrad_products([dlt] * 9, [xin] * 9, n_pts, iters=5, timed=True, f16s=True)

@@ -180,10 +180,18 @@ __device__ __forceinline__ void pack_stage(const float h0, const float h1, const
     if constexpr (STAGE == 0) asm volatile("v_fma_f32 %0, %2, %6, %3\n\tv_fma_f32 %1, %4, %6, %5" : "=&v"(t.y0), "=&v"(t.y1) : "v"(l0), "v"(h0), "v"(l1), "v"(h1), "s"(dn));
     else if constexpr (STAGE == 1) asm volatile("v_fma_f32 %0, %2, %6, %3\n\tv_fma_f32 %1, %4, %6, %5" : "=&v"(t.Y0), "=&v"(t.Y1) : "v"(h0), "v"(l0), "v"(h1), "v"(l1), "s"(up));
     else if constexpr (STAGE == 2) {
+#ifdef MN_F16S_MAXNUM_RELU                                     // timing builds only (A/B of the NaN-propagating ReLU): the pre-round-4 instructions
+        if (RELU) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2\n\tv_pk_max_f16 %0, %0, 0" : "=&v"(t.hi) : "v"(t.y0), "v"(t.y1));
+#else
         if (RELU) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2\n\tv_pk_maximum3_f16 %0, %0, 0, 0" : "=&v"(t.hi) : "v"(t.y0), "v"(t.y1));
+#endif
         else asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=&v"(t.hi) : "v"(t.y0), "v"(t.y1));
     } else if constexpr (STAGE == 3) {
+#ifdef MN_F16S_MAXNUM_RELU
+        if (RELU) asm volatile("v_max_f32 %0, %0, 0\n\tv_max_f32 %1, %1, 0" : "+v"(t.Y0), "+v"(t.Y1));
+#else
         if (RELU) asm volatile("v_maximum3_f32 %0, %0, 0, 0\n\tv_maximum3_f32 %1, %1, 0, 0" : "+v"(t.Y0), "+v"(t.Y1));
+#endif
     } else if constexpr (STAGE == 4) {
         // lo halves: f16((y - hi) * 2^11) = f16(fma(hi, -2^11, Y)): the residual is exact, rounded once.  mixlo writes bits 15:0 of the
         // destination, mixhi bits 31:16 (each keeps the other half): the pair lands packed.

@@ -349,7 +349,7 @@ def test_wgrad_product_vs_float64(P, M, N):
 
 def test_wgrad_products_batched_entry_equals_the_single_products():
     """mi_nerf_wgrad_products (several wide products over the same points in one launch -- the form the backward pass uses) against
-    the stand-alone entry, product by product, and against float64."""
+    the same entry with ONE product per call, product by product, and against float64."""
     g = torch.Generator().manual_seed(5)
     P = 5000
     shapes = [(256, 256), (256, 128), (128, 256), (200, 252), (256, 256)]
@@ -361,8 +361,15 @@ def test_wgrad_products_batched_entry_equals_the_single_products():
         want = d[:P].double().T @ x[:P].double()
         assert rel_err(o, want) < 2e-5 and rel_err(b, d[:P].double().sum(0)) < 2e-5
         assert rel_err(o, o1) < 1e-5 and rel_err(b, b1) < 1e-5                   # different slice counts: same sums up to summation order
-    with pytest.raises(Exception):
-        ops.wgrad_products([deltas[0][:, :32].contiguous()], [xs[0]], P)            # a narrow side: not for the batched entry
+    # products with a narrow side (gamma(x), gamma(d), the heads) in the same call: each in a launch of its own behind the wide batch, bit-identical
+    # to the product alone; not in split precision
+    nd, nx = deltas[0][:, :32].contiguous(), xs[0][:, :63].contiguous()
+    mixed, mb, _ = ops.wgrad_products([deltas[0], nd, deltas[1], deltas[2]], [xs[0], xs[0], nx, xs[2]], P)
+    assert torch.equal(mixed[0], ops.wgrad_product(deltas[0], 256, xs[0], 256, P)[0]) and torch.equal(mixed[3], ops.wgrad_product(deltas[2], 128, xs[2], 256, P)[0])
+    assert rel_err(mixed[1], nd[:P].double().T @ xs[0][:P].double()) < 2e-5 and rel_err(mixed[2], deltas[1][:P].double().T @ nx[:P].double()) < 2e-5
+    assert rel_err(mb[1], nd[:P].double().sum(0)) < 2e-5 and rel_err(mb[2], deltas[1][:P].double().sum(0)) < 2e-5
+    with pytest.raises(Exception, match="split-precision entry takes wide products"):
+        ops.wgrad_products([nd], [xs[0]], P, f16s=True)
     # the same batch in split precision (wgrad_f16s_kernel through mi_nerf_wgrad_products_f16s): fp32-grade against float64, also with
     # gradient operands of very different magnitudes in one batch (one scale for the batch, from its largest entry) and tiny ones
     for scale in (1.0, 1e-6):
