@@ -649,7 +649,9 @@ def worker(args) -> None:
         pcfg = R.PathConfig()
         with torch.no_grad():
             R.render_rays(rc[:256], sd, pcfg, tc[:256], uc[:256])                            # warm-up
-            reps, spent, n_cpu = [], 0.0, 1024
+            # the WHOLE 4096-ray batch per call, the reference's own chunk size (chunk_rays = 4096): a 1024-ray sample
+            # (rounds 1-3) gave the CPU smaller GEMMs per call than the reference runs and read 30 % low
+            reps, spent, n_cpu = [], 0.0, main.n
             while spent < 12.0 and len(reps) < 3:
                 t0 = time.perf_counter()
                 R.render_rays(rc[:n_cpu], sd, pcfg, tc[:n_cpu], uc[:n_cpu])
@@ -668,8 +670,8 @@ def worker(args) -> None:
         cpu = {"value": round(n_cpu / float(np.median(reps)), 1), "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
                "train_rays_per_s": train_cpu,
                "sample": f"oracle/restate.py render_rays (torch CPU fp32, {torch.get_num_threads()} threads: this job's share of the host) on the first "
-                         f"{n_cpu} rays of the same 4096-ray batch, median of {len(reps)} reps; SURVEY section 6 timed the reference itself at "
-                         "691 rays/s on 8 vCPU with its own 4096-ray chunks (larger GEMMs per call than this 1024-ray sample)"}
+                         f"{n_cpu} rays of the same 4096-ray batch (the reference's chunk size), median of {len(reps)} rep(s), {spent:.0f} s of CPU work; "
+                         "SURVEY section 6 timed the reference itself at 691 rays/s on 8 vCPU of the build container"}
 
     if rank == 0 or solo:
         head_value = value if headline_strong else value_weak

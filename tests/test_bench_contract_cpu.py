@@ -12,7 +12,7 @@ REQUIRED = {"metric": str, "value": (int, float), "unit": str, "n_gpus": int, "s
 
 @pytest.mark.parametrize("name", ["r02_bench_n1.json", "r02_bench_n1_bf16.json", "r02_bench_n1_fern.json", "r02_bench_n2_gloo_rehearsal.json",
                                   "r03_bench_n1.json", "r03_bench_n1_bf16.json", "r03_bench_n1_fern.json", "r03_bench_n4_gloo_rehearsal.json",
-                                  "r03_bench_rank3_of_8_alone.json", "r03_bench_n1_with_f16_split.json"])
+                                  "r03_bench_rank3_of_8_alone.json", "r03_bench_n1_with_f16_split.json", "r04_bench_n1.json", "r04_bench_n4_gloo_rehearsal.json"])
 def test_committed_bench_line_has_the_contract_fields(name):
     path = os.path.join(ROOT, "profiles", name)
     with open(path) as f:
@@ -40,6 +40,15 @@ def test_committed_bench_line_has_the_contract_fields(name):
         assert "f16" in leg["dtype"] and leg["rays_per_s"] > 2 * line["value"]
         assert abs(leg["issued_f16_mfma_TFLOPs"] - 3 * leg["network_TFLOPs"]) < 0.5
         assert leg["max_abs_rgb_c_diff_vs_f32"] < 2e-6 and leg["rays_beyond_1e-4_rgb_f"] < 0.005 * 4096
+    if name.startswith("r04") and line["n_gpus"] > 1:     # an N > 1 line verifies itself: what the collective saw, from the driver's record alone
+        c = line["collective"]
+        assert c["world_size"] == line["n_gpus"] and c["backend"] in ("nccl", "gloo")
+        assert [r["rank"] for r in c["ranks"]] == list(range(line["n_gpus"])) and all({"host", "device", "name", "pci_bus_id", "cus"} <= set(r) for r in c["ranks"])
+        assert 1 <= c["distinct_devices"] <= line["n_gpus"]
+        assert c["all_gather_ms"] > 0 and c["all_gather_bytes_assembled"] >= line["frame_hw"][0] * line["frame_hw"][1] * 16
+        assert c["frame_equal_across_ranks"] is True and c["neighbour_tile_recomputed_equal"] is True
+    if name.startswith("r04") and line["n_gpus"] == 1:
+        assert "collective" not in line                   # the N = 1 line is unchanged
     if line["n_gpus"] == 1 and "cpu_baseline" in line:
         cpu = line["cpu_baseline"]
         for key in ("value", "unit", "cores", "kind", "sample"):

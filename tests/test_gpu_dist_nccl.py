@@ -121,6 +121,23 @@ def test_bench_one_rank_through_rccl():
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["value"] > 1e5
+    assert "collective" not in line                       # --frames 0: nothing to gather
+
+
+@pytest.mark.timeout(900)
+def test_bench_collective_block_through_rccl_with_one_rank():
+    """The `collective` object of an N > 1 line against RCCL itself, in a group of one rank (what a one-GPU box can show): backend "nccl",
+    the device all-gathered, the tile all-gather timed by hipEvents, the frame checksum and the re-rendered block equal."""
+    env = dict(os.environ, BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--frames", "1", "--train-steps", "0",
+                        "--no-cpu-baseline", "--no-small-batch", "--no-bf16-leg", "--no-f16s-leg"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    c = line["collective"]
+    assert c["backend"] == "nccl" and c["world_size"] == 1 and c["distinct_devices"] == 1 and c["ranks"][0]["cus"] == 256
+    assert c["frame_equal_across_ranks"] is True and c["neighbour_tile_recomputed_equal"] is True
+    assert 0 < c["all_gather_ms"] < 50 and c["all_gather_bytes_assembled"] == 800 * 800 * 16
 
 
 @pytest.mark.timeout(900)

@@ -160,6 +160,13 @@ def test_bench_four_live_ranks(workload):
     assert j["config"]["rays_per_gpu"] == 1024 and j["value"] > 0 and j["value_weak"] > 0
     assert j["frame_ms"] > 0 and j["frame_hw"] == ([378, 504] if workload == "fern" else [800, 800])
     assert 0 < j["roofline"]["frac"] <= 1.0 and j["bf16"]["rays_per_s"] > 0
+    # the line verifies its own collective: four ranks seen, the gathered frame identical on all of them, every rank's re-render of its
+    # neighbour's row block (ragged for fern) equal to that block of the gathered frame
+    c = j["collective"]
+    assert c["world_size"] == 4 and c["backend"] == ("nccl" if torch.cuda.device_count() >= 4 else "gloo")
+    assert [r["rank"] for r in c["ranks"]] == [0, 1, 2, 3] and all(r["cus"] == 256 for r in c["ranks"])
+    assert c["distinct_devices"] == (4 if torch.cuda.device_count() >= 4 else 1)
+    assert c["frame_equal_across_ranks"] is True and c["neighbour_tile_recomputed_equal"] is True and c["all_gather_ms"] > 0
 
 
 @pytest.mark.timeout(900)
@@ -168,6 +175,7 @@ def test_bench_one_rank_of_eight_alone(workload, rank):
     """Rank r of the driver's 8-GPU run, alone on this GPU: the 512-ray shard (both legs), its 100 (lego) or 47-48 (fern) frame rows."""
     j = _bench(["--gpus", "8", "--steps", "3", "--warmup", "1", "--frames", "1", "--no-cpu-baseline", "--workload", workload],
                {"BENCH_SOLO_RANK": "1", "RANK": str(rank), "LOCAL_RANK": "0", "WORLD_SIZE": "8"})
-    assert j["n_gpus"] == 8 and j["config"]["rays_per_gpu"] == 512 and j["solo_rank"] == {**j["solo_rank"], "rank": rank, "of": 8}
+    assert j["n_gpus"] == 8 and j["config"]["rays_per_gpu"] == 512 and j["solo_rank"] == {**j["solo_rank"], "rank": rank, "of": 8, "n_gpus_measured": 1}
+    assert "collective" not in j
     assert j["value"] > 0 and j["value_weak"] > 0 and j["frame_ms"] > 0
     assert j["bf16"]["rays_per_s"] > 0 and 0 < j["roofline"]["frac"] <= 1.0
