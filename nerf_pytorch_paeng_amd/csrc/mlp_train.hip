@@ -410,7 +410,11 @@ __device__ __forceinline__ void wgrad_f16s_body(const WgradArgs& a, const unsign
     const unsigned slice = flat - (unsigned)b * gridDim.x;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = wm * 128, n0 = wn * 128;
+#ifdef MN_WGF_NODUP                                            // timing build only (results are garbage): every operand row fetched by ONE of the two waves that
+    const bool aok = m0 + 4 * i < a.M[b] && wn == 0, bok = n0 + 4 * i < a.N[b] && wm == 0;      // need it -- the upper bound of what sharing it through LDS could save
+#else
     const bool aok = m0 + 4 * i < a.M[b], bok = n0 + 4 * i < a.N[b];
+#endif
     const float* abase = a.dlt[b];
     const float* bbase = a.x[b];
     const long long ldd = a.ldd[b], ldx = a.ldx[b];
