@@ -755,6 +755,9 @@ int stage_composite_fine_z(const float* raw_c, const float* z_c, const float* ra
     MN_CHECK_ARG(n >= 0 && Sc >= 3 && Sc <= 1024 && Nf >= 1 && Sc + Nf <= MAX_LDS_FLOATS_PER_RAY, "bad sizes (Sc=%d Nf=%d)", Sc, Nf);
     int n2 = 2;
     while (n2 < Sc + Nf) n2 <<= 1;
+    // (tighter than stage_fine_z's 2 (Sc - 1) + n2, but never the binding limit of mi_nerf_render_rays: its fine compositing takes at most
+    // 1024 depths per ray (stage_composite), so Sc + Nf <= 1024, n2 <= 1024 and 3 Sc - 2 + n2 <= 4094 -- every sample count the staged
+    // sequence rendered, the fused launch renders too; tests/test_gpu_parity.py test_largest_sample_counts)
     MN_CHECK_ARG(Sc + 2 * (Sc - 1) + n2 <= MAX_LDS_FLOATS_PER_RAY, "bad sizes (Sc=%d Nf=%d: 3 Sc - 2 + %d must not exceed %d)", Sc, Nf, n2,
                  MAX_LDS_FLOATS_PER_RAY);
     if (n == 0) return MI_NERF_OK;

@@ -168,6 +168,30 @@ def test_fine_z_sort_is_torch_sort(n, Sc, Nf):
         assert not bool(torch.isnan(zf[1:]).any())
 
 
+@pytest.mark.parametrize("Sc,Nf", [(512, 512), (1000, 24), (341, 683), (3, 1021)])
+def test_largest_sample_counts_fused_equals_staged(Sc, Nf):
+    """mi_nerf_render_rays composites, resamples and merges in ONE launch (composite_fine_z_kernel), whose LDS need (3 Sc - 2 + pow2(Sc + Nf)
+    floats per ray) is larger than the staged fine_z kernel's.  The fine compositing takes at most 1024 depths, and within Sc + Nf <= 1024
+    the fused bound always holds: the largest sample counts render, bit-identical to the staged sequence of entry points."""
+    n = 6
+    sd = synthetic.make_state_dict(2, 4, 128, skips=())
+    packed = weights.PackedNeRF.from_state_dict(sd, DEV)
+    K, H, W = synthetic.lego_camera()
+    pix = T(synthetic.pixel_batch(H, W, n, 3)).to(DEV)
+    o, d = ops.make_o_d_pixels(W, H, K, synthetic.pose_spherical(10.0, -30.0, 4.0), pix)
+    rays = torch.cat([o, d], -1).contiguous()
+    t_rand, u = T(R.counter_uniform(1, 0, 0, n, Sc)).to(DEV), T(R.counter_uniform(1, 1, 0, n, Nf)).to(DEV)
+    out = NP.render_rays(rays, packed, None, make_opts(N_samples_c=Sc, N_samples_f=Nf), t_rand=t_rand, u=u)
+    z_c = ops.stratified_z(2.0, 6.0, t_rand)
+    rgb_c, disp_c, _, w_c, _ = ops.composite(ops.mlp_rays(packed.net, packed.coarse, rays, z_c), z_c, rays, want_all=True)
+    z_f = ops.fine_z(z_c, w_c, Nf, False, u)
+    rgb_f, disp_f, *_ = ops.composite(ops.mlp_rays(packed.net, packed.fine, rays, z_f), z_f, rays)
+    assert torch.equal(out["rgb_c"], rgb_c) and torch.equal(out["disp_c"], disp_c)
+    assert torch.equal(out["rgb_f"], rgb_f) and torch.equal(out["disp_f"], disp_f) and torch.isfinite(rgb_f).all()
+    with pytest.raises(Exception):                                             # one depth more than the compositing kernel takes
+        NP.render_rays(rays, packed, None, make_opts(N_samples_c=Sc, N_samples_f=Nf + 1), t_rand=t_rand)
+
+
 def test_posenc_embed_F5(golden):
     g = golden("F5_posenc")
     f10, d10 = get_positional_encoder(10)
