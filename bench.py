@@ -172,10 +172,13 @@ def collective_block(dist, mdist, torch, dev, backend, rank, world, H, W, K, pos
                                 not depend on which GPU rendered which rows (dist.py's bit-identity claim, checked on the hardware)"""
     import statistics
     cdev = dev if backend == "nccl" else torch.device("cpu")
-    props = torch.cuda.get_device_properties(dev)
-    bus = getattr(props, "pci_bus_id", None)
-    me = {"rank": rank, "host": socket.gethostname(), "device": f"cuda:{dev.index}", "name": props.name,
-          "pci_bus_id": None if bus is None else int(bus), "cus": int(props.multi_processor_count)}
+    me = {"rank": rank, "host": "?", "device": f"cuda:{dev.index}", "name": "?", "pci_bus_id": None, "cus": 0}
+    try:                                                   # rank-local look-ups must not be able to stop a rank short of the collectives below
+        props = torch.cuda.get_device_properties(dev)
+        bus = getattr(props, "pci_bus_id", None)
+        me.update(host=socket.gethostname(), name=str(props.name), pci_bus_id=None if bus is None else int(bus), cus=int(props.multi_processor_count))
+    except Exception as e:                                 # noqa: BLE001
+        me["error"] = repr(e)
     ranks = [None] * world
     dist.all_gather_object(ranks, me)
     pose_last = pose
@@ -515,7 +518,7 @@ def worker(args) -> None:
 
     # ---- N > 1: what the collective saw, so that the first multi-GPU run verifies itself from the driver's record ------------------------
     collective = None
-    if use_dist and args.frames > 0:
+    if use_dist and args.frames > 0 and os.environ.get("BENCH_NO_COLLECTIVE_BLOCK") != "1":
         collective = collective_block(dist, mdist, torch, dev, backend, rank, world, H, W, K, pose, packed, opts, args.bf16, rgb, disp)
 
     # ---- training step: forward + backward + Adam on this rank's 4096-ray batch --------------

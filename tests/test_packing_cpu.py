@@ -317,6 +317,15 @@ def test_mfma_hazard_checker_sees_a_planted_hazard():
     assert not H.check(listing(mf, other, other, other, "v_mov_b32_e32 v9, v54"))[1]
     assert H.check(listing(mf, other, other, "v_mov_b32_e32 v9, v54"))[1]
     assert H.check(listing(mf, other, other, other, "v_mov_b32_e32 v9, v54"), strict=True)[1]
+    # 6. the builtin-MFMA kernels' accumulators live in AGPRs and are read out by explicit v_accvgpr_read statements: an f32-input 32x32x2
+    #    (16 passes, not on the XDL pipe) needs P + 2 = 18 wait states -- hipcc's own `s_nop 15; s_nop 1`
+    f32 = "v_mfma_f32_32x32x2_f32 a[32:47], v27, v131, a[32:47]"
+    assert not H.check(listing(f32, "s_nop 15", "s_nop 1", "v_accvgpr_read_b32 v32, a32"))[1]
+    assert H.check(listing(f32, "s_nop 15", "s_nop 0", "v_accvgpr_read_b32 v32, a32"))[1]
+    assert not H.check(listing(f32, f32, "s_nop 1", "v_accvgpr_read_b32 v32, a32"))[1]          # a second one holds the wave 16 wait states
+    # 7. a packed fragment written into the AGPR file is an MFMA operand two wait states later at the earliest
+    wr = "v_accvgpr_write_b32 a120, v5"
+    assert H.check(listing(wr, mf))[1] and H.check(listing(wr, "s_nop 0", mf))[1] and not H.check(listing(wr, "s_nop 1", mf))[1]
 
 
 @pytest.mark.parametrize("backward", [False, True])

@@ -1,0 +1,14 @@
+#!/bin/bash
+# Host-side AddressSanitizer + UBSan run of the library's packers, argument checks and layout code (CPU only: GPU ASan is not available on
+# this pool).  Builds build_scratch/libmi_nerf_asan.so with the HOST code instrumented (-fno-gpu-sanitize keeps the device code as shipped)
+# and runs the CPU tests that go through the C ABI against it.  Round 4: 43 tests, no finding.
+set -e
+cd "$(dirname "$0")/.."
+LIB=$(python - <<'PY'
+from nerf_pytorch_paeng_amd import build
+print(build.build_variant("asan", ["-fsanitize=address", "-fsanitize=undefined", "-fno-gpu-sanitize", "-fno-omit-frame-pointer", "-g1"]))
+PY
+)
+ASAN=$(/opt/rocm/lib/llvm/bin/clang --print-file-name=libclang_rt.asan-x86_64.so)
+MI_NERF_LIB=$LIB LD_PRELOAD=$ASAN ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
+    python -m pytest tests/test_packing_cpu.py tests/test_model_cpu.py tests/test_harness_cpu.py -x -q
