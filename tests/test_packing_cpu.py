@@ -322,7 +322,9 @@ def test_mfma_hazard_checker_sees_a_planted_hazard():
     f32 = "v_mfma_f32_32x32x2_f32 a[32:47], v27, v131, a[32:47]"
     assert not H.check(listing(f32, "s_nop 15", "s_nop 1", "v_accvgpr_read_b32 v32, a32"))[1]
     assert H.check(listing(f32, "s_nop 15", "s_nop 0", "v_accvgpr_read_b32 v32, a32"))[1]
-    assert not H.check(listing(f32, f32, "s_nop 1", "v_accvgpr_read_b32 v32, a32"))[1]          # a second one holds the wave 16 wait states
+    f32b = "v_mfma_f32_32x32x2_f32 a[48:63], v27, v131, a[48:63]"
+    assert not H.check(listing(f32, f32b, "s_nop 1", "v_accvgpr_read_b32 v32, a32"))[1]         # another tile's MFMA holds the wave 16 wait states
+    assert H.check(listing(f32, f32b, "s_nop 0", "v_accvgpr_read_b32 v32, a32"))[1]
     # 7. a packed fragment written into the AGPR file is an MFMA operand two wait states later at the earliest
     wr = "v_accvgpr_write_b32 a120, v5"
     assert H.check(listing(wr, mf))[1] and H.check(listing(wr, "s_nop 0", mf))[1] and not H.check(listing(wr, "s_nop 1", mf))[1]
