@@ -156,3 +156,28 @@ def test_bench_launches_its_own_workers():
     assert j["n_gpus"] == 2 and j["steps"] == 3 and j["scaling"] == "strong"
     assert j["config"]["rays_per_gpu"] == 2048 and j["value"] > 0 and j["value_weak"] > 0
     assert j["frame_ms_800x800"] > 0 and j["roofline"]["frac"] <= 1.0
+
+
+@pytest.mark.timeout(900)
+def test_bench_under_torch_distributed_run():
+    """The driver's own form for N > 1: `python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P
+    bench.py --gpus 2 ...` -- the workers are used as launched (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment), rank 0
+    prints ONE line, and the line carries the self-verifying `collective` block.  gloo when the box has one GPU (the ranks share it)."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    if torch.cuda.device_count() < 2:
+        env["BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--frames", "1",
+                        "--no-cpu-baseline", "--no-bf16-leg", "--no-f16s-leg"], env=env, capture_output=True, text=True, timeout=850, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["scaling"] == "strong" and j["config"]["rays_per_gpu"] == 2048
+    c = j["collective"]
+    assert c["world_size"] == 2 and [x["rank"] for x in c["ranks"]] == [0, 1]
+    assert c["frame_equal_across_ranks"] is True and c["neighbour_tile_recomputed_equal"] is True
