@@ -12,6 +12,10 @@ MLP -> composite -> inverse-CDF resampling with its jitter draw, :162-163, + mer
 depths -> composite) over one batch whose rays are resident in HBM; the jitter is drawn INSIDE the step, by the
 sampling kernels themselves (counter-based generator keyed on the global ray index).
 
+Timing: W untimed warm-up steps, then EXACTLY K timed steps between barrier + torch.cuda.synchronize() on both sides, max over ranks.  In front
+of the W warm-up steps the same step runs for 60 ms (BENCH_PREWARM_S; untimed, like them; `config.prewarm_ms`): the clock governor takes tens of
+milliseconds to come up from idle and five steps of a 512-ray shard are 5 ms (profiles/r04_prewarm_512_ray_shard.txt); the 4096-ray step is unaffected.
+
 Scaling: the 4096-ray batch is SHARDED over the N GPUs -- 4096/N contiguous rays per rank
 (512 at N = 8), no data-path collective -- so `value` = 4096 * K / max-over-ranks time is STRONG scaled.
 `value_weak` (every rank renders its own 4096-ray batch, N * 4096 * K / time) is measured in a second leg of
@@ -60,6 +64,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0           # dense bf16 MFMA peak (the headline 5 
 LDS_DMA_CHIP_TBPS = 34.8                 # chip-wide L2 -> LDS fill rate MEASURED with the kernel's own geometry, 4 waves per CU issuing (tools/mfma_probe6 "dma",
                                          # profiles/r03_bf16_hybrid_probe.txt); the 6.4 TB/s of MI355X_MICROARCH.md is for one loader wave per CU
 BF16_POINTS_PER_PASS = 256               # mlp_bf16.hip: a workgroup takes 4 waves x 64 points through one pass of the weight stream
+PREWARM_S = float(os.environ.get("BENCH_PREWARM_S", "0.06"))                 # untimed steps in front of the W warm-up steps: clock ramp from idle (timed_steps)
 LAUNCHER_GRACE_S = float(os.environ.get("BENCH_LAUNCHER_GRACE_S", "10"))     # SIGTERM -> SIGKILL for the survivors of a failed run
 KERNEL_SOURCES = ("mlp_fp32.hip", "mlp_core.h", "layout.h", "common.h")
 
@@ -298,7 +303,16 @@ def worker(args) -> None:
         ops.render_rays(packed.net, blobs[0], blobs[1], b.cfg, b.rays, None, None, workspace=b.ws, out=b.out)
 
     def timed_steps(b, warmup: int, steps: int) -> float:
-        """W untimed + EXACTLY K timed steps, barrier + synchronize on both sides, max over ranks (seconds)."""
+        """W untimed + EXACTLY K timed steps, barrier + synchronize on both sides, max over ranks (seconds).
+        In front of the W warm-up steps the same step runs for PREWARM_S of wall time (untimed, like them): the GPU's clock governor needs
+        tens of milliseconds to come up from idle, and W = 5 steps of a 512-ray shard (what a rank renders at N = 8) are 5 ms -- measured
+        on one GPU: 1.127 ms per step behind 5 warm-up steps, 1.064 behind 50 (profiles/r04_prewarm_512_ray_shard.txt).  A 4096-ray step
+        (42 ms of warm-up at W = 5) does not move."""
+        t_pw = time.perf_counter()
+        while time.perf_counter() - t_pw < PREWARM_S:
+            for _ in range(4):
+                step(b)
+            torch.cuda.synchronize(dev)
         for _ in range(warmup):
             step(b)
         torch.cuda.synchronize(dev)
@@ -691,6 +705,7 @@ def worker(args) -> None:
                                     "lego coarse+fine 4096-ray batch, 64+128 samples, 8x256 MLP (BASELINE config #2)") +
                                    (" -- bf16 MFMA variant (config #5)" if args.bf16 else ""),
                        "rays_per_gpu": per_gpu, "rays_per_gpu_weak": N_RAYS, "samples": [SC, NF], "net": "8x256, skip 4, L_x 10, L_d 4",
+                       "prewarm_ms": round(1e3 * PREWARM_S, 1),
                        "parallelism": (f"the 4096-ray batch split into {world} contiguous slices of {per_gpu} rays, one per GPU, no data-path collective "
                                        f"(value); value_weak: {N_RAYS} rays on each of {world} GPU(s); frame: rows over {world} GPU(s) + one all-gather")},
             "frame_ms_800x800": None if (frame_ms is None or fern) else round(frame_ms, 2),
