@@ -144,7 +144,11 @@ int mi_nerf_mlp_rays_bf16_shape(const mi_nerf_net* net, const void* packed_bf16_
  * runs at 1/16 of the f16 rate).  Weights and activations travel as f16 pairs x = hi + lo * 2^-11, a product is three
  * v_mfma_f32_16x16x32_f16 with fp32 accumulation (hi.hi, hi.lo, lo.hi; the dropped lo.lo term is 2^-22 of the product): the error
  * against an fp64 evaluation is that of the fp32 kernel.  W = 256; |weights| and |activations| must stay below the f16 maximum
- * (65 504; the packer refuses larger weights).  An extra precision mode like the bf16 variant, not the default path. */
+ * (65 504).  Range contract: the host packer refuses larger weights (the device packer counts them: out_of_range_dev below); an
+ * ACTIVATION at or beyond 65 520 comes out as NaN in every output that depends on it -- all four raw values of the point for a trunk
+ * unit, the three colours for a linear_feat / linear_d unit -- never as a finite value (the kernels' ReLU is the NaN-propagating
+ * maximum); a pre-activation <= -65 520 in front of a ReLU is exact (the unit is off, as in fp32).  An extra precision mode like the
+ * bf16 variant, not the default path. */
 size_t mi_nerf_packed_bytes_f16s(const mi_nerf_net* net);
 int mi_nerf_pack_weights_f16s(const mi_nerf_net* net, const mi_nerf_params* params, void* host_blob, size_t blob_bytes);
 int mi_nerf_mlp_rays_f16s(const mi_nerf_net* net, const void* packed_f16s_dev, const float* rays_dev, const float* z_dev,
