@@ -1,0 +1,100 @@
+"""Error behaviour of the C ABI ("returning int, 0 = ok, non-zero = HIP / argument error; no exceptions across the ABI, error
+text via a last_error() accessor"), checked WITHOUT a GPU: every entry point that takes a pointer is called with plausible scalars and NULL
+pointers and must answer MI_NERF_EINVAL (1) with a message -- which also proves that the NULL / size checks sit in front of the first HIP
+call (on this box a call that got as far as a launch answers MI_NERF_EHIP, "no ROCm-capable device").  No call here can reach a kernel."""
+import ctypes as C
+
+import pytest
+
+from nerf_pytorch_paeng_amd import _lib, ops
+
+EINVAL, EHIP = 1, 2
+# scalar arguments (by position) that must be valid for the NULL check to be the one that fires
+OVERRIDES = {
+    "mi_nerf_composite": {3: 6},                       # ray_stride
+    "mi_nerf_composite_backward": {3: 6},
+    "mi_nerf_render_rays": {9: 1 << 30},               # workspace_bytes
+    "mi_nerf_pack_map": {1: 0, 3: 1 << 24},            # kind, map_len
+    "mi_nerf_mlp_rays_train": {8: 1 << 30},            # stash_bytes
+    "mi_nerf_mlp_rays_train_f16s": {8: 1 << 30},
+    "mi_nerf_mlp_embedded_train": {6: 1 << 30},
+    "mi_nerf_mlp_backward": {10: 1 << 34},             # work_bytes
+    "mi_nerf_mlp_backward_mode": {10: 1 << 34, 12: 0, 13: 0},     # work_bytes, stage, mode
+    "mi_nerf_mlp_embedded_backward": {8: 1 << 34},
+    "mi_nerf_rays_rgb": {0: 8, 1: 8, 5: 2},            # W, H, n_img
+    "mi_nerf_time_mlp_rays": {7: 1, 8: 0},             # iters, use_bf16
+    "mi_nerf_fill_uniform": {4: 8},
+    "mi_nerf_wgrad_products": {0: 1},
+    "mi_nerf_wgrad_products_f16s": {0: 1},
+}
+
+
+def _pointer_entries():
+    out = []
+    for name, (restype, argtypes) in _lib.SIGNATURES.items():
+        if restype is C.c_int and any(a not in (C.c_int, C.c_int64, C.c_float, C.c_uint32, C.c_size_t) for a in argtypes):
+            out.append(name)
+    return out
+
+
+def _args(name, net, cfg):
+    args = []
+    for i, a in enumerate(_lib.SIGNATURES[name][1]):
+        if i in OVERRIDES.get(name, {}):
+            args.append(OVERRIDES[name][i])
+        elif a is _lib._NETP:
+            args.append(C.byref(net))
+        elif a is _lib._CFGP:
+            args.append(C.byref(cfg))
+        elif a in (C.c_int, C.c_int64, C.c_uint32):
+            args.append(4)
+        elif a is C.c_size_t:
+            args.append(0)
+        elif a is C.c_float:
+            args.append(1.0)
+        else:
+            args.append(None)                              # every data pointer NULL
+    return args
+
+
+@pytest.mark.parametrize("name", _pointer_entries())
+def test_null_pointers_are_refused_before_any_hip_call(name):
+    if name == "mi_nerf_selftest_mfma":
+        pytest.skip("takes only a stream: nothing to refuse")
+    lib = _lib.lib()
+    net, cfg = ops.make_net(8, 256, 4), ops.render_cfg(2.0, 6.0, 64, 128, False, False)
+    rc = getattr(lib, name)(*_args(name, net, cfg))
+    msg = lib.mi_nerf_last_error().decode()
+    assert rc == EINVAL, (name, rc, msg)
+    assert msg and "HIP error" not in msg, (name, msg)
+
+
+@pytest.mark.parametrize("name", [n for n in _pointer_entries() if _lib._NETP in _lib.SIGNATURES[n][1]])
+def test_null_net_and_unsupported_shapes_are_refused(name):
+    lib = _lib.lib()
+    cfg = ops.render_cfg(2.0, 6.0, 64, 128, False, False)
+    good = ops.make_net(8, 256, 4)
+    a = _args(name, good, cfg)
+    a[list(_lib.SIGNATURES[name][1]).index(_lib._NETP)] = None
+    assert getattr(lib, name)(*a) == EINVAL and lib.mi_nerf_last_error()
+    for bad in (ops.make_net(8, 192, 4), ops.make_net(0, 256, -1), ops.make_net(40, 256, 4)):        # a width / depths no kernel is built for
+        b = _args(name, bad, cfg)
+        assert getattr(lib, name)(*b) == EINVAL, (name, bad.D, bad.W)
+
+
+def test_the_error_text_is_per_thread():
+    """mi_nerf_last_error() is thread-local: a failure on another thread does not overwrite this thread's message."""
+    import threading
+    lib = _lib.lib()
+    net = ops.make_net(8, 256, 4)
+    assert lib.mi_nerf_mlp_rays(C.byref(net), None, None, None, -5, 64, None, None) == EINVAL
+    mine = lib.mi_nerf_last_error()
+    assert b"n_rays=-5" in mine
+    seen = {}
+
+    def other():
+        lib.mi_nerf_stratified_z(4, 64, 2.0, 6.0, None, None, None)
+        seen["msg"] = lib.mi_nerf_last_error()
+    t = threading.Thread(target=other)
+    t.start(); t.join()
+    assert b"t_rand" in seen["msg"] and lib.mi_nerf_last_error() == mine
