@@ -27,6 +27,19 @@ def main():
         out["kernels"].append({"name": name[:120], "launches": len(rs), "total_ms": round(sum(d) / 1e6, 4), "avg_us": round(sum(d) / len(d) / 1e3, 2),
                                "median_us": round(d[len(d) // 2] / 1e3, 2), "min_us": round(d[0] / 1e3, 2), "max_us": round(d[-1] / 1e3, 2),
                                **{k: rs[-1][ix[k]] for k in ("grid_size_x", "workgroup_size_x", "lds_size", "scratch_size", "vgpr_count", "accum_vgpr_count", "sgpr_count") if k in ix}})
+    if "--clusters" in sys.argv:                  # launches of one kernel NAME span many shapes (a 256-ray shard ... a whole frame): group each
+        for k in out["kernels"]:                  # kernel's durations into clusters of +-2 % and report the populous ones (count, mean, spread)
+            d = sorted(r[ix["duration"]] for r in by[[n for n in by if n[:120] == k["name"]][0]])
+            cl, cur = [], [d[0]]
+            for v in d[1:]:
+                if v <= cur[0] * 1.04:
+                    cur.append(v)
+                else:
+                    cl.append(cur)
+                    cur = [v]
+            cl.append(cur)
+            k["clusters"] = [{"launches": len(c), "mean_us": round(sum(c) / len(c) / 1e3, 2), "min_us": round(c[0] / 1e3, 2), "max_us": round(c[-1] / 1e3, 2)}
+                             for c in sorted(cl, key=lambda c: -len(c))[:8] if len(c) >= 3]
     if "--timeline" in sys.argv:                  # the last N dispatches in time order: start relative to the first of them, duration, gap to the previous end
         n = int(sys.argv[sys.argv.index("--timeline") + 1])
         tl = sorted(rows, key=lambda r: r[ix["start"]])[-n:]
