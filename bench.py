@@ -162,6 +162,14 @@ def bf16_stream(blob, n_points: int, kernel_ms: float) -> dict:
             "chip_lds_dma_rate_TBps_measured": LDS_DMA_CHIP_TBPS, "frac_of_lds_dma_rate": round(tbps / LDS_DMA_CHIP_TBPS, 3)}
 
 
+def frame_checksum(torch, rgb, disp) -> int:
+    """Order-sensitive 64-bit checksum over the fp32 BIT PATTERNS of an assembled frame (rgb [H,W,3], disp [H,W]): equal checksums on two
+    lines -- an N = 1 run and an N = 8 run of the same command -- mean the frames are bit-identical whatever the number of GPUs."""
+    t = torch.cat([rgb.reshape(-1, 3), disp.reshape(-1, 1)], -1)
+    b = t.contiguous().view(torch.int32).to(torch.int64).reshape(-1)
+    return int((b * (torch.arange(b.numel(), device=b.device, dtype=torch.int64) % 1000003 + 1)).sum().item())
+
+
 def collective_block(dist, mdist, torch, dev, backend, rank, world, H, W, K, pose, packed, opts, bf16, rgb_last, disp_last) -> dict:
     """The `collective` object of an N > 1 line (every rank calls this; the dict is the same on all of them).
 
@@ -202,12 +210,7 @@ def collective_block(dist, mdist, torch, dev, backend, rank, world, H, W, K, pos
     tm = torch.tensor([statistics.median(times)], dtype=torch.float64, device=cdev)
     dist.all_reduce(tm, op=dist.ReduceOp.MAX)
 
-    def checksum(t):                                       # order-sensitive 64-bit sum over the fp32 bit patterns
-        b = t.contiguous().view(torch.int32).to(torch.int64).reshape(-1)
-        return int((b * (torch.arange(b.numel(), device=b.device, dtype=torch.int64) % 1000003 + 1)).sum().item())
-
-    frame_last = torch.cat([rgb_last.reshape(H * W, 3), disp_last.reshape(H * W, 1)], -1)
-    cs = torch.tensor([checksum(frame_last)], dtype=torch.int64, device=cdev)
+    cs = torch.tensor([frame_checksum(torch, rgb_last, disp_last)], dtype=torch.int64, device=cdev)
     cs0 = cs.clone()
     dist.broadcast(cs0, src=0)
     nb = (rank + 1) % world
@@ -498,7 +501,7 @@ def worker(args) -> None:
             bf16_leg["small_batch"] = legs16
 
     # ---- 800x800 frame, rows sharded over the ranks, one all-gather of the tiles ----------------------------
-    frame_ms = None
+    frame_ms = frame_cs = None
     def frame(fp):
         if solo:                                                        # this rank's row block only; nothing to gather
             return mdist.render_shard(H, W, K, fp, packed, opts, world, rank, seed=0, bf16=args.bf16), None
@@ -516,6 +519,8 @@ def worker(args) -> None:
         barrier()
         frame_ms = 1e3 * max_over_ranks(time.perf_counter() - t0) / args.frames
         assert (rgb.shape == (H, W, 3) or solo) and torch.isfinite(rgb).all()
+        if not solo:
+            frame_cs = frame_checksum(torch, rgb, disp)                 # of the LAST timed frame: the same pose for any N at the same --frames
         if f16s_leg is not None and not solo:                           # the same frame(s) in split precision, held against the fp32 frame just rendered
             mdist.render_frame(H, W, K, pose, packed, opts, seed=0, f16s=True)
             torch.cuda.synchronize(dev)
@@ -710,6 +715,7 @@ def worker(args) -> None:
                                        f"(value); value_weak: {N_RAYS} rays on each of {world} GPU(s); frame: rows over {world} GPU(s) + one all-gather")},
             "frame_ms_800x800": None if (frame_ms is None or fern) else round(frame_ms, 2),
             "frame_ms": None if frame_ms is None else round(frame_ms, 2), "frame_hw": [H, W],
+            "frame_checksum": frame_cs,                # bit patterns of the last timed frame: compare across N (and with collective.frame_checksum_rank0)
             "frac_of_roofline_end_to_end": round(head_value / world * FLOP_PER_RAY / 1e12 / peak, 4),
             "roofline": roofline,
         }

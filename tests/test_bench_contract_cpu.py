@@ -47,6 +47,10 @@ def test_committed_bench_line_has_the_contract_fields(name):
         assert 1 <= c["distinct_devices"] <= line["n_gpus"]
         assert c["all_gather_ms"] > 0 and c["all_gather_bytes_assembled"] >= line["frame_hw"][0] * line["frame_hw"][1] * 16
         assert c["frame_equal_across_ranks"] is True and c["neighbour_tile_recomputed_equal"] is True
+    if name.startswith("r04") and "solo_rank" not in line:
+        assert isinstance(line["frame_checksum"], int)    # the assembled frame's bit patterns: comparable across N
+        if line["n_gpus"] > 1:
+            assert line["frame_checksum"] == line["collective"]["frame_checksum_rank0"]
     if name.startswith("r04") and line["n_gpus"] == 1:
         assert "collective" not in line                   # the N = 1 line is unchanged
     if line["n_gpus"] == 1 and "cpu_baseline" in line:

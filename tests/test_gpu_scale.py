@@ -167,6 +167,13 @@ def test_bench_four_live_ranks(workload):
     assert [r["rank"] for r in c["ranks"]] == [0, 1, 2, 3] and all(r["cus"] == 256 for r in c["ranks"])
     assert c["distinct_devices"] == (4 if torch.cuda.device_count() >= 4 else 1)
     assert c["frame_equal_across_ranks"] is True and c["neighbour_tile_recomputed_equal"] is True and c["all_gather_ms"] > 0
+    # ... and the frame it assembled from four tiles is, bit for bit, the frame ONE rank renders: `frame_checksum` (the fp32 bit patterns
+    # of the last timed frame) of this line against a one-GPU run of the same command -- what BENCH (N = 1) and SCALE (N = 8) let a
+    # reader check from the driver's records alone
+    assert j["frame_checksum"] == c["frame_checksum_rank0"] and isinstance(j["frame_checksum"], int)
+    one = _bench(["--gpus", "1", "--steps", "3", "--warmup", "1", "--frames", "1", "--no-cpu-baseline", "--train-steps", "0", "--no-small-batch",
+                  "--no-bf16-leg", "--no-f16s-leg", "--workload", workload], {})
+    assert "collective" not in one and one["frame_checksum"] == j["frame_checksum"], (one["frame_checksum"], j["frame_checksum"])
 
 
 @pytest.mark.timeout(900)
