@@ -170,6 +170,66 @@ def frame_checksum(torch, rgb, disp) -> int:
     return int((b * (torch.arange(b.numel(), device=b.device, dtype=torch.int64) % 1000003 + 1)).sum().item())
 
 
+C_ABI_LEG_TIMEOUT_S = 120.0
+TILE_GATHER_ROUTE = "c_abi" if os.environ.get("BENCH_TILE_GATHER") == "c_abi" else "torch"
+_c_abi_leg_hung = False
+
+
+def c_abi_gather_leg(dist, mdist, torch, dev, local, full_torch, H, W) -> dict:
+    """The tile all-gather through the C ABI (mi_nerf_comm_* / mi_nerf_all_gather_tiles) next to the torch.distributed route, on every rank.
+    The ranks agree (all-reduce MIN of a flag) that RCCL is loadable BEFORE the collective communicator set-up, so that a rank without it cannot
+    leave the others waiting inside ncclCommInitRank; the whole leg runs on a watched thread: a hang costs this sub-object, not the line."""
+    import statistics
+    import threading
+    out = {}
+
+    def leg():
+        try:
+            torch.cuda.set_device(dev)
+            ok = 1
+            try:
+                mdist.TileComm.unique_id()                 # loads librccl (first use) and proves ncclGetUniqueId answers
+            except Exception as e:                         # noqa: BLE001
+                ok, out["error"] = 0, repr(e)
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                out.setdefault("error", "RCCL not loadable on another rank")
+                return
+            comm = mdist.tile_comm(dev)
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            times = []
+            for i in range(12):
+                torch.cuda.synchronize(dev)
+                dist.barrier()
+                ev[0].record()
+                full = comm.all_gather_tiles(local, H, W)
+                ev[1].record()
+                torch.cuda.synchronize(dev)
+                if i >= 2:
+                    times.append(ev[0].elapsed_time(ev[1]))
+            tm = torch.tensor([statistics.median(times)], dtype=torch.float64, device=dev)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            eq = torch.tensor([int(torch.equal(full, full_torch))], dtype=torch.int32, device=dev)
+            dist.all_reduce(eq, op=dist.ReduceOp.MIN)
+            mdist.close_tile_comms()
+            out.update(all_gather_ms=round(float(tm.item()), 4), equal_to_torch_route_on_every_rank=bool(eq.item()), world_size=comm.world,
+                       staging_bytes=int(mdist.lib().mi_nerf_all_gather_staging_bytes(comm.world, H, W, int(local.shape[1]))),
+                       what="mi_nerf_all_gather_tiles: libmi_nerf.so's own RCCL communicator (unique id broadcast over the process group), "
+                            "enqueued on the stream the tile was rendered on; hipEvents on that stream, median of 10, max over ranks")
+        except Exception as e:                             # noqa: BLE001
+            out["error"] = repr(e)
+
+    t = threading.Thread(target=leg, daemon=True)
+    t.start()
+    t.join(C_ABI_LEG_TIMEOUT_S)
+    if t.is_alive():
+        global _c_abi_leg_hung
+        _c_abi_leg_hung = True
+        return {"error": f"did not finish within {C_ABI_LEG_TIMEOUT_S:.0f} s"}
+    return out
+
+
 def collective_block(dist, mdist, torch, dev, backend, rank, world, H, W, K, pose, packed, opts, bf16, rgb_last, disp_last) -> dict:
     """The `collective` object of an N > 1 line (every rank calls this; the dict is the same on all of them).
 
@@ -182,7 +242,12 @@ def collective_block(dist, mdist, torch, dev, backend, rank, world, H, W, K, pos
                                 an equality flag against rank 0's checksum)
     neighbour_tile_recomputed_equal   every rank re-renders the row block of rank (r + 1) % N on ITS OWN GPU and compares it bit for bit
                                 with that block of the gathered frame: the gather put each tile where it belongs, and the frame does
-                                not depend on which GPU rendered which rows (dist.py's bit-identity claim, checked on the hardware)"""
+                                not depend on which GPU rendered which rows (dist.py's bit-identity claim, checked on the hardware)
+    tile_gather_route           which route assembled the TIMED frames: "torch" (torch.distributed all_gather_into_tensor) or "c_abi"
+                                (BENCH_TILE_GATHER=c_abi: mi_nerf_all_gather_tiles, the library's own RCCL communicator, on the render stream)
+    c_abi                       backend "nccl" only: the same tile gathered by the C ABI's route (include/mi_nerf.h, csrc/comm.hip) -- timed like
+                                all_gather_ms and compared bit for bit with the torch route's frame on every rank; {"error": ...} instead of
+                                a dead run when RCCL cannot be loaded or the leg does not finish within C_ABI_LEG_TIMEOUT_S"""
     import statistics
     cdev = dev if backend == "nccl" else torch.device("cpu")
     me = {"rank": rank, "host": "?", "device": f"cuda:{dev.index}", "name": "?", "pci_bus_id": None, "cus": 0}
@@ -219,7 +284,11 @@ def collective_block(dist, mdist, torch, dev, backend, rank, world, H, W, K, pos
     flags = torch.tensor([int(cs.item() == cs0.item()), int(torch.equal(mine, full[r0 * W:(r0 + nr) * W]))], dtype=torch.int32, device=cdev)
     dist.all_reduce(flags, op=dist.ReduceOp.MIN)
     max_rows = (H + world - 1) // world
+    c_abi = None
+    if backend == "nccl" and os.environ.get("BENCH_NO_C_ABI_GATHER") != "1":
+        c_abi = c_abi_gather_leg(dist, mdist, torch, dev, local, full, H, W)
     return {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks": ranks,
+            "tile_gather_route": TILE_GATHER_ROUTE, "c_abi": c_abi,
             "distinct_devices": len({(r["host"], r["device"] if r["pci_bus_id"] is None else r["pci_bus_id"]) for r in ranks}),
             "all_gather_ms": round(float(tm.item()), 4), "all_gather_bytes_per_rank": max_rows * W * 4 * 4, "all_gather_bytes_assembled": world * max_rows * W * 4 * 4,
             "all_gather_timing": "hipEvents around dist.gather_tiles on torch's current stream (the collective is ordered on it), median of 10, max over ranks",
@@ -505,7 +574,7 @@ def worker(args) -> None:
     def frame(fp):
         if solo:                                                        # this rank's row block only; nothing to gather
             return mdist.render_shard(H, W, K, fp, packed, opts, world, rank, seed=0, bf16=args.bf16), None
-        return mdist.render_frame(H, W, K, fp, packed, opts, seed=0, bf16=args.bf16)
+        return mdist.render_frame(H, W, K, fp, packed, opts, seed=0, bf16=args.bf16, via=TILE_GATHER_ROUTE if backend == "nccl" else "torch")
 
     if args.frames > 0:
         frame(pose)                                                     # warm-up frame
@@ -739,8 +808,12 @@ def worker(args) -> None:
         if cpu is not None:
             line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)
+    if _c_abi_leg_hung:                # a collective of the optional C-ABI leg never returned: its stream cannot be drained; the line is out
+        sys.stdout.flush()
+        os._exit(0)
     if use_dist:
         barrier()                      # rank 0 may still be printing / staging: tear the group down together
+        mdist.close_tile_comms()
         dist.destroy_process_group()
 
 

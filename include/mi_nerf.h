@@ -20,12 +20,15 @@
 extern "C" {
 #endif
 
-#define MI_NERF_ABI_VERSION 2   /* 2: mi_nerf_render_cfg grew seed / reserved / ray_offset (in-kernel jitter) */
+#define MI_NERF_ABI_VERSION 3   /* 2: mi_nerf_render_cfg grew seed / reserved / ray_offset (in-kernel jitter)
+                                   3: mi_nerf_wgrad_product removed, mi_nerf_wgrad_products takes narrow products and needs
+                                      mi_nerf_wgrad_scratch_bytes(); the RCCL tile-gather helpers (mi_nerf_comm_*, mi_nerf_all_gather_tiles) */
 
 /* status codes */
 #define MI_NERF_OK 0
 #define MI_NERF_EINVAL 1   /* bad argument / unsupported shape */
 #define MI_NERF_EHIP 2     /* HIP runtime error (launch, etc.) */
+#define MI_NERF_ERCCL 3    /* RCCL not loadable, or an RCCL call failed (mi_nerf_comm_*, mi_nerf_all_gather_tiles only) */
 
 int mi_nerf_abi_version(void);
 /* Thread-local text of the last error on this thread ("" if none). */
@@ -321,6 +324,33 @@ int mi_nerf_rays_rgb(int W, int H, const float k4[4], const float* poses_dev, co
                      float* rays_rgb_dev, void* stream);
 /* np.random.shuffle(rays_rgb) (main.py:102; utils.py:47-52): dst[i] = src[perm[i]], rows of row_floats floats; perm int64 */
 int mi_nerf_permute_rows(const float* src_dev, const int64_t* perm_dev, int64_t n, int row_floats, float* dst_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Multi-GPU frame assembly (SURVEY.md section 8(b) "thin RCCL helpers", 8(e)).  The reference is single-GPU (main.py:166-170): no
+ * counterpart.  One process per GPU; every rank renders the contiguous row block
+ *     rows(r) = H / world + (r < H % world),   row0(r) = r * (H / world) + min(r, H % world)
+ * of an H x W frame (for a flat ray batch: H = rays, W = 1), and the ONLY exchange is one all-gather of the [rows(r) * W, C] fp32
+ * tiles -- C = 4: rgb + disp, 1.28 MB per rank for 800 x 800 over 8 GPUs.  librccl is resolved at FIRST USE (dlopen of librccl.so.1:
+ * the copy the process already holds -- PyTorch's -- else ROCm's; MI_NERF_RCCL_LIB overrides), so a one-GPU user needs no RCCL; when it
+ * cannot be loaded these entries return MI_NERF_ERCCL.  The collective is enqueued on `stream` -- pass the stream the render ran on: no
+ * host synchronisation separates the last composite launch from the gather.
+ *   bootstrap: rank 0 calls mi_nerf_comm_unique_id and hands the MI_NERF_COMM_ID_BYTES to every rank by any channel (MPI, a TCP store,
+ *   torch.distributed); each rank calls mi_nerf_comm_init_rank with its device current (hipSetDevice) -- collective over all ranks.
+ * ---------------------------------------------------------------------------------------------- */
+#define MI_NERF_COMM_ID_BYTES 128
+int mi_nerf_comm_unique_id(void* id_host);
+int mi_nerf_comm_init_rank(const void* id_host, int world, int rank, void** comm_out);
+int mi_nerf_comm_info(void* comm, int* world_out, int* rank_out, int* device_out);      /* any out pointer may be NULL */
+int mi_nerf_comm_destroy(void* comm);
+/* tile [rows_local * W, C] (rows_local must be rows(rank)) -> frame [H * W, C] on every rank.  H % world == 0: ONE ncclAllGather straight
+ * into frame_dev (in place, no copy at all, when tile_dev == frame_dev + row0 * W * C: render into the frame); staging unused (may be
+ * NULL).  Ragged split (fern's 378 rows over 8 ranks: 48, 48, 47 x 6): the tiles are padded to the largest block inside `staging`
+ * (caller-allocated, mi_nerf_all_gather_staging_bytes, 16-byte aligned), gathered in place there and un-padded into frame_dev by one copy
+ * kernel (mi_nerf_unpad_tiles, exported so that a one-GPU box can check the ragged geometry for any world size). */
+size_t mi_nerf_all_gather_staging_bytes(int world, int H, int W, int C);                /* 0 when H % world == 0 */
+int mi_nerf_all_gather_tiles(void* comm, const float* tile_dev, int rows_local, int H, int W, int C, float* frame_dev, void* staging_dev,
+                             size_t staging_bytes, void* stream);
+int mi_nerf_unpad_tiles(const float* staging_dev, int world, int H, int W, int C, float* frame_dev, void* stream);
 
 /* Timing hook used by bench.py: average device time (ms) of `iters` back-to-back launches of the fused MLP
  * kernel on `stream`, measured with hipEvents recorded on that same stream (torch.cuda.Event only sees

@@ -14,7 +14,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 # MI_NERF_LIB: an A/B variant built by `python -m nerf_pytorch_paeng_amd.build --variant TAG ...` (same ABI, same checks)
 LIB_PATH = os.environ.get("MI_NERF_LIB") or os.path.join(HERE, "libmi_nerf.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class MiNerfError(RuntimeError):
@@ -112,6 +112,13 @@ SIGNATURES = {
     "mi_nerf_to8b": (_I, [_P, _I64, _P, _P, _P]),
     "mi_nerf_rays_rgb": (_I, [_I, _I, C.POINTER(_F), _P, _P, _I64, _P, _P]),
     "mi_nerf_permute_rows": (_I, [_P, _P, _I64, _I, _P, _P]),
+    "mi_nerf_comm_unique_id": (_I, [_P]),
+    "mi_nerf_comm_init_rank": (_I, [_P, _I, _I, C.POINTER(_P)]),
+    "mi_nerf_comm_info": (_I, [_P, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
+    "mi_nerf_comm_destroy": (_I, [_P]),
+    "mi_nerf_all_gather_staging_bytes": (_SZ, [_I, _I, _I, _I]),
+    "mi_nerf_all_gather_tiles": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _SZ, _P]),
+    "mi_nerf_unpad_tiles": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "mi_nerf_time_mlp_rays": (_I, [_NETP, _P, _P, _P, _I64, _I, _P, _I, _I, C.POINTER(_F), _P]),
     "mi_nerf_selftest_mfma": (_I, [_P]),
 }

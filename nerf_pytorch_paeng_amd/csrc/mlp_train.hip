@@ -833,7 +833,7 @@ struct WideProduct { const float* dlt; int ldd, M; const float* x; int ldx, N; f
 
 // absmax: NULL = fp32 MFMA (wgrad_big_kernel); else the device word holding max|d_raw| and the products run in split precision
 static int run_wgrad_batch(const WideProduct* pr, int n, long long P, float* partial, hipStream_t st, const unsigned* absmax = nullptr) {
-    MN_CHECK_ARG(n >= 1 && n <= WG_MAXB, "internal: %d products in a batch", n);
+    MN_CHECK_ARG(n >= 1 && n <= WG_MAXB, "%d wide products in one batch (at most WG_MAXB)", n);
     WgradArgs a{};
     ReduceBatch rb{};
     int max_total = 0;
@@ -841,7 +841,7 @@ static int run_wgrad_batch(const WideProduct* pr, int n, long long P, float* par
         const WideProduct& q = pr[b];
         MN_CHECK_ARG(q.M <= 256 && q.N <= 256 && q.M % 4 == 0 && q.N % 4 == 0 && q.ldd % 4 == 0 && q.ldx % 4 == 0 &&
                      ((uintptr_t)q.dlt & 15) == 0 && ((uintptr_t)q.x & 15) == 0,
-                     "internal: wgrad operands must be at most 256 wide, 16-byte aligned, with pitches of 4 floats");
+                     "wgrad operands must be at most 256 wide, 16-byte aligned, with pitches of 4 floats");
         a.dlt[b] = q.dlt; a.x[b] = q.x; a.ldd[b] = q.ldd; a.ldx[b] = q.ldx; a.M[b] = q.M; a.N[b] = q.N; a.want_bias[b] = q.bias != nullptr;
         rb.out[b] = q.out; rb.bias[b] = q.bias; rb.ldo[b] = q.ldo; rb.M[b] = q.M; rb.N[b] = q.N;
         const int total = q.M * q.N + (q.bias ? q.M : 0);
@@ -878,7 +878,7 @@ static int run_wgrad(const float* dlt, int ldd, int M, const float* x, int ldx, 
     a.nar = delta_is_wide ? x : dlt;  a.ldn = delta_is_wide ? ldx : ldd; a.Nn = delta_is_wide ? N : M;
     a.P = P;
     MN_CHECK_ARG(a.Mw <= 256 && a.Nn <= 64 && a.Mw % 4 == 0 && a.ldw % 4 == 0 && ((uintptr_t)a.wide & 15) == 0,
-                 "internal: unsupported narrow wgrad shape %d x %d", M, N);
+                 "unsupported narrow wgrad shape %d x %d", M, N);
     const int WQ = a.Mw > 128 ? 2 : 1, NN = a.Nn > 32 ? 2 : 1;
     const int Wp = 128 * WQ, Np = 32 * NN;
     const size_t per_slice = (size_t)Wp * Np + Wp + Np;

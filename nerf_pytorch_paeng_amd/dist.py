@@ -4,16 +4,28 @@ The path shards embarrassingly (every ray is independent end to end; SURVEY.md 8
 GPU, each renders a contiguous block of image rows generated on its own device from (K, pose, row
 range) -- no input scatter, no collective during compute -- followed by ONE all-gather of the
 ``[rows_local * W, 4]`` fp32 output tile (rgb + disp; 1.28 MB per GPU for 800x800 over 8 GPUs) over
-RCCL/xGMI (``torch.distributed`` backend "nccl" on ROCm).  The jitter is keyed on the global ray index,
-so the assembled frame is bit-identical for any world size.  The reference is single-GPU only
-(main.py:166-170); this module has no counterpart there.
+RCCL/xGMI.  The jitter is keyed on the global ray index, so the assembled frame is bit-identical for any
+world size.  The reference is single-GPU only (main.py:166-170); this module has no counterpart there.
+
+Two routes to the same collective (``gather_tiles(..., via=)``):
+
+* ``"c_abi"`` -- ``mi_nerf_all_gather_tiles`` of libmi_nerf.so (csrc/comm.hip): an RCCL communicator of the library's own
+  (``TileComm``; bootstrapped from a 128-byte unique id that rank 0 creates and any channel distributes -- here a
+  ``torch.distributed`` broadcast), the all-gather enqueued on the HIP stream the render ran on, ragged splits padded and
+  un-padded by the library.  What a caller of the C ABI that is not PyTorch uses.
+* ``"torch"`` -- ``torch.distributed.all_gather_into_tensor`` (backend "nccl" is RCCL on ROCm; "gloo" for CPU rehearsals).
 """
 from __future__ import annotations
 
-from typing import Callable, Optional, Sequence, Tuple
+import ctypes as C
+from typing import Callable, Dict, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
+
+from ._lib import MiNerfError, check, dev_ptr, lib, stream_ptr
+
+COMM_ID_BYTES = 128          # MI_NERF_COMM_ID_BYTES
 
 
 def shard_rows(H: int, world: int, rank: int) -> Tuple[int, int]:
@@ -29,13 +41,110 @@ def shard_range(n: int, world: int, rank: int) -> Tuple[int, int]:
     return shard_rows(n, world, rank)
 
 
-def gather_tiles(local: torch.Tensor, H: int, W: int, group=None, force_collective: bool = False) -> torch.Tensor:
+class TileComm:
+    """An RCCL communicator of libmi_nerf.so for the tile gather (mi_nerf_comm_* / mi_nerf_all_gather_tiles, include/mi_nerf.h).
+    ``TileComm(id_bytes, world, rank, device)`` is collective over all ranks; ``TileComm.unique_id()`` makes the id on rank 0.
+    ``close()`` destroys the communicator (collective too: call it on every rank, before the process group goes away)."""
+
+    def __init__(self, id_bytes: bytes, world: int, rank: int, device):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise MiNerfError(f"TileComm lives on a HIP device, got {self.device}")
+        if len(id_bytes) != COMM_ID_BYTES:
+            raise MiNerfError(f"the unique id has {COMM_ID_BYTES} bytes, got {len(id_bytes)}")
+        self.world, self.rank = int(world), int(rank)
+        self._staging: Optional[torch.Tensor] = None
+        handle = C.c_void_p()
+        with torch.cuda.device(self.device):
+            check(lib().mi_nerf_comm_init_rank(C.c_char_p(bytes(id_bytes)), self.world, self.rank, C.byref(handle)), "mi_nerf_comm_init_rank")
+        self._handle = handle
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(COMM_ID_BYTES)
+        check(lib().mi_nerf_comm_unique_id(buf), "mi_nerf_comm_unique_id")
+        return buf.raw
+
+    @classmethod
+    def from_group(cls, device, group=None) -> "TileComm":
+        """Bootstrap over an initialised ``torch.distributed`` group: rank 0's id travels in one 128-byte broadcast."""
+        device = torch.device(device)
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        carrier = device if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        t = torch.zeros(COMM_ID_BYTES, dtype=torch.uint8, device=carrier)
+        if rank == 0:
+            t.copy_(torch.frombuffer(bytearray(cls.unique_id()), dtype=torch.uint8))
+        dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        return cls(bytes(t.cpu().numpy().tobytes()), world, rank, device)
+
+    def all_gather_tiles(self, local: torch.Tensor, H: int, W: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """``[rows_local * W, C]`` -> ``[H * W, C]`` on every rank, enqueued on the current stream of the tile's device."""
+        if self._handle is None:
+            raise MiNerfError("the communicator is closed")
+        if local.dim() != 2 or local.shape[0] % W:
+            raise MiNerfError(f"tile must be [rows_local * {W}, C], got {tuple(local.shape)}")
+        Cc = int(local.shape[1])
+        rows = local.shape[0] // W
+        frame = torch.empty(H * W, Cc, dtype=torch.float32, device=local.device) if out is None else out
+        need = int(lib().mi_nerf_all_gather_staging_bytes(self.world, H, W, Cc))
+        if need and (self._staging is None or self._staging.numel() < need):
+            self._staging = torch.empty(need, dtype=torch.uint8, device=local.device)
+        with torch.cuda.device(local.device):
+            check(lib().mi_nerf_all_gather_tiles(self._handle, dev_ptr(local, "tile"), rows, H, W, Cc, dev_ptr(frame, "frame"),
+                                                 dev_ptr(self._staging, "staging", torch.uint8, 16) if need else None, need,
+                                                 stream_ptr(local.device)), "mi_nerf_all_gather_tiles")
+        return frame
+
+    def close(self) -> None:
+        if self._handle is not None:
+            h, self._handle = self._handle, None
+            with torch.cuda.device(self.device):
+                check(lib().mi_nerf_comm_destroy(h), "mi_nerf_comm_destroy")
+
+
+def unpad_tiles(staging: torch.Tensor, world: int, H: int, W: int, C_: int) -> torch.Tensor:
+    """``staging`` [world, max_rows * W * C] (every rank's tile padded to the largest block, as the ragged all-gather leaves it) ->
+    frame [H * W, C]: the copy kernel behind mi_nerf_all_gather_tiles on its own (any world size on one GPU)."""
+    frame = torch.empty(H * W, C_, dtype=torch.float32, device=staging.device)
+    with torch.cuda.device(staging.device):
+        check(lib().mi_nerf_unpad_tiles(dev_ptr(staging, "staging"), int(world), int(H), int(W), int(C_), dev_ptr(frame), stream_ptr(staging.device)),
+              "mi_nerf_unpad_tiles")
+    return frame
+
+
+_tile_comms: Dict[Tuple[int, int], TileComm] = {}
+
+
+def tile_comm(device, group=None) -> TileComm:
+    """The process's TileComm for (group, device), created on first use (collective over the group)."""
+    device = torch.device(device)
+    key = (id(group) if group is not None else 0, device.index if device.index is not None else torch.cuda.current_device())
+    if key not in _tile_comms:
+        _tile_comms[key] = TileComm.from_group(device, group)
+    return _tile_comms[key]
+
+
+def close_tile_comms() -> None:
+    """Destroy every cached TileComm (call on every rank before dist.destroy_process_group())."""
+    while _tile_comms:
+        _tile_comms.popitem()[1].close()
+
+
+def gather_tiles(local: torch.Tensor, H: int, W: int, group=None, force_collective: bool = False, via: str = "torch") -> torch.Tensor:
     """All-gather per-rank ``[rows_local * W, C]`` tiles into the full ``[H * W, C]`` frame on every rank.
     A group of one rank returns its tile as is; ``force_collective`` sends it through the collective anyway (a one-GPU box can
-    then exercise the RCCL call path itself)."""
+    then exercise the RCCL call path itself).  ``via``: "torch" (torch.distributed) or "c_abi" (mi_nerf_all_gather_tiles on the
+    current stream; HIP tensors only)."""
+    if via not in ("torch", "c_abi"):
+        raise ValueError(f"via must be 'torch' or 'c_abi', got {via!r}")
     if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force_collective):
         return local
     world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if via == "c_abi":
+        _, n_rows = shard_rows(H, world, rank)
+        if local.shape[0] != n_rows * W:
+            raise ValueError(f"rank {rank}: tile has {local.shape[0]} rays, expected {n_rows * W}")
+        return tile_comm(local.device, group).all_gather_tiles(local.contiguous(), H, W)
     C = local.shape[1]
     max_rows = (H + world - 1) // world
     _, n_rows = shard_rows(H, world, rank)
@@ -90,7 +199,7 @@ def render_shard(H: int, W: int, K, pose, model, opts, world: int, rank: int, *,
 
 
 def render_frame(H: int, W: int, K, pose, model, opts, *, seed: int = 0, group=None, bf16: bool = False, f16s: bool = False,
-                 render_rows_fn: Optional[Callable[[int, int], torch.Tensor]] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+                 render_rows_fn: Optional[Callable[[int, int], torch.Tensor]] = None, via: str = "torch") -> Tuple[torch.Tensor, torch.Tensor]:
     """Render one H x W frame sharded over the process group; returns (rgb [H,W,3], disp [H,W]) on every rank.
 
     Counterpart of the per-pose body of the reference's test()/render() harness (test.py:38-53,143-152):
@@ -105,5 +214,5 @@ def render_frame(H: int, W: int, K, pose, model, opts, *, seed: int = 0, group=N
         local = render_shard(H, W, K, pose, model, opts, world, rank, seed=seed, bf16=bf16, f16s=f16s)
     else:
         local = render_rows_fn(*shard_rows(H, world, rank))
-    full = gather_tiles(local, H, W, group)
+    full = gather_tiles(local, H, W, group, via=via)
     return full[:, :3].reshape(H, W, 3), full[:, 3].reshape(H, W)

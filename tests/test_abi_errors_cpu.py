@@ -82,6 +82,28 @@ def test_null_net_and_unsupported_shapes_are_refused(name):
         assert getattr(lib, name)(*b) == EINVAL, (name, bad.D, bad.W)
 
 
+def test_tile_gather_helpers_refuse_bad_arguments_before_touching_rccl():
+    """mi_nerf_comm_* / mi_nerf_all_gather_tiles (SURVEY.md 8(b) "thin RCCL helpers"): argument errors are MI_NERF_EINVAL with a message, and are
+    found before librccl is even looked for (this box has no GPU; an RCCL or HIP call would answer 3 or 2)."""
+    lib = _lib.lib()
+    ident = C.create_string_buffer(128)
+    handle = C.c_void_p()
+    for world, rank in ((0, 0), (2, 2), (2, -1)):
+        assert lib.mi_nerf_comm_init_rank(ident, world, rank, C.byref(handle)) == EINVAL and handle.value is None
+        assert b"rank" in lib.mi_nerf_last_error()
+    assert lib.mi_nerf_comm_init_rank(None, 2, 0, C.byref(handle)) == EINVAL
+    fake = C.create_string_buffer(64)                                   # not a handle of mi_nerf_comm_init_rank
+    assert lib.mi_nerf_all_gather_tiles(fake, None, 1, 8, 8, 4, None, None, 0, None) == EINVAL and b"handle" in lib.mi_nerf_last_error()
+    assert lib.mi_nerf_comm_destroy(fake) == EINVAL and lib.mi_nerf_comm_info(fake, None, None, None) == EINVAL
+    # staging: nothing for equal blocks; world x largest block for a ragged split (fern: 378 rows over 8 ranks -> 8 x 48 rows)
+    assert lib.mi_nerf_all_gather_staging_bytes(8, 800, 800, 4) == 0
+    assert lib.mi_nerf_all_gather_staging_bytes(8, 378, 504, 4) == 8 * 48 * 504 * 4 * 4
+    assert lib.mi_nerf_all_gather_staging_bytes(1, 378, 504, 4) == 0
+    assert lib.mi_nerf_all_gather_staging_bytes(8, 4096, 1, 4) == 0 and lib.mi_nerf_all_gather_staging_bytes(3, 4096, 1, 4) == 3 * 1366 * 16
+    assert lib.mi_nerf_all_gather_staging_bytes(0, 8, 8, 4) == 0 and lib.mi_nerf_all_gather_staging_bytes(16, 8, 8, 4) == 0      # refused geometry
+    assert lib.mi_nerf_unpad_tiles(fake, 16, 8, 8, 4, fake, None) == EINVAL and b"cannot be split" in lib.mi_nerf_last_error()
+
+
 def test_the_error_text_is_per_thread():
     """mi_nerf_last_error() is thread-local: a failure on another thread does not overwrite this thread's message."""
     import threading

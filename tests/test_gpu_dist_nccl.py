@@ -42,7 +42,7 @@ def _scene(dev, H, W):
     return packed, K, pose, opts
 
 
-def _nccl_worker(rank, world, port, H, W, out_dir):
+def _nccl_worker(rank, world, port, H, W, out_dir, via="torch"):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
@@ -53,21 +53,24 @@ def _nccl_worker(rank, world, port, H, W, out_dir):
     try:
         from nerf_pytorch_paeng_amd.dist import render_frame
         packed, K, pose, opts = _scene(dev, H, W)
-        rgb, disp = render_frame(H, W, K, pose, packed, opts, seed=3)
+        rgb, disp = render_frame(H, W, K, pose, packed, opts, seed=3, via=via)
         torch.cuda.synchronize(dev)
         np.save(os.path.join(out_dir, f"rgb_{rank}.npy"), rgb.cpu().numpy())
         np.save(os.path.join(out_dir, f"disp_{rank}.npy"), disp.cpu().numpy())
         dist.barrier()
     finally:
+        from nerf_pytorch_paeng_amd.dist import close_tile_comms
+        close_tile_comms()
         dist.destroy_process_group()
 
 
 @pytest.mark.timeout(600)
+@pytest.mark.parametrize("via", ["torch", "c_abi"])         # torch.distributed's all-gather | mi_nerf_all_gather_tiles of the C ABI
 @pytest.mark.parametrize("H,W", [(24, 20), (25, 12)])      # even and ragged row splits
-def test_nccl_two_rank_frame_is_bit_identical_to_one_rank(tmp_path, H, W):
+def test_nccl_two_rank_frame_is_bit_identical_to_one_rank(tmp_path, H, W, via):
     if torch.cuda.device_count() < 2:
         pytest.skip("needs two GPUs (RCCL wants one GPU per rank); runs on the multi-GPU node")
-    mp.spawn(_nccl_worker, args=(2, _free_port(), H, W, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_nccl_worker, args=(2, _free_port(), H, W, str(tmp_path), via), nprocs=2, join=True)
     from nerf_pytorch_paeng_amd.dist import render_frame
     dev = torch.device("cuda:0")
     packed, K, pose, opts = _scene(dev, H, W)
@@ -111,6 +114,91 @@ def test_rccl_call_path_with_one_rank(tmp_path):
     np.testing.assert_array_equal(np.load(tmp_path / "tile.npy"), np.load(tmp_path / "full.npy"))
 
 
+def _c_abi_one_rank_worker(_index, port, out_dir):
+    """The C ABI's own communicator in a group of one rank: (a) bootstrapped over torch.distributed and used through gather_tiles(via="c_abi"),
+    (b) stand-alone from a unique id with no process group at all, (c) in place (the tile already lies in the frame), (d) on a side stream."""
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    from nerf_pytorch_paeng_amd import dist as mdist
+    res = {}
+    gen = torch.Generator(device=dev).manual_seed(0)
+    # (b) first, before any process group exists: the helpers need nothing from torch.distributed
+    comm = mdist.TileComm(mdist.TileComm.unique_id(), 1, 0, dev)
+    for name, (H, W) in (("lego", (800, 800)), ("fern", (378, 504))):
+        tile = torch.rand(H * W, 4, generator=gen, device=dev)
+        res[f"alone_{name}"] = bool(torch.equal(comm.all_gather_tiles(tile, H, W), tile))
+    frame = torch.rand(800 * 800, 4, generator=gen, device=dev)                  # (c) sendbuff == recvbuff: RCCL's in-place form
+    want = frame.clone()
+    res["in_place"] = bool(torch.equal(comm.all_gather_tiles(frame, 800, 800, out=frame), want)) and frame.data_ptr() == frame.data_ptr()
+    side = torch.cuda.Stream(dev)                                                 # (d) ordered on the stream the producer ran on
+    with torch.cuda.stream(side):
+        tile = torch.rand(378 * 504, 4, generator=gen, device=dev) * 2.0 + 1.0
+        out = comm.all_gather_tiles(tile, 378, 504)
+    side.synchronize()
+    res["side_stream"] = bool(torch.equal(out, tile))
+    try:
+        comm.all_gather_tiles(tile[:-504], 378, 504)
+        res["bad_rows_refused"] = False
+    except mdist.MiNerfError as e:
+        res["bad_rows_refused"] = "owns 378 of 378 rows" in str(e)
+    comm.close()
+    try:
+        comm.all_gather_tiles(tile, 378, 504)
+        res["closed_refused"] = False
+    except mdist.MiNerfError:
+        res["closed_refused"] = True
+    # (a) the route dist.render_frame / bench.py take
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        for name, (H, W) in (("lego", (800, 800)), ("fern", (378, 504))):
+            tile = torch.rand(H * W, 4, generator=gen, device=dev)
+            a = mdist.gather_tiles(tile, H, W, force_collective=True, via="c_abi")
+            b = mdist.gather_tiles(tile, H, W, force_collective=True, via="torch")
+            torch.cuda.synchronize(dev)
+            res[f"group_{name}"] = bool(torch.equal(a, b) and torch.equal(a, tile))
+        mdist.close_tile_comms()
+    finally:
+        dist.destroy_process_group()
+    with open(os.path.join(out_dir, "res.json"), "w") as f:
+        json.dump(res, f)
+
+
+@pytest.mark.timeout(600)
+def test_c_abi_tile_gather_with_one_rank(tmp_path):
+    """mi_nerf_comm_unique_id / _init_rank / mi_nerf_all_gather_tiles / _destroy against RCCL itself (librccl resolved at first use), in a
+    group of ONE rank -- all a one-GPU box can run: bit-equal to torch.distributed's all-gather for the 800-row and the 378-row frame."""
+    mp.spawn(_c_abi_one_rank_worker, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    res = json.load(open(tmp_path / "res.json"))
+    assert res and all(res.values()), res
+    assert set(res) == {"alone_lego", "alone_fern", "in_place", "side_stream", "bad_rows_refused", "closed_refused", "group_lego", "group_fern"}
+
+
+@pytest.mark.parametrize("world,H,W,C", [(8, 378, 504, 4), (8, 800, 800, 4), (3, 4096, 1, 4), (4, 25, 3, 1), (6, 800, 800, 3), (5, 7, 1, 1)])
+def test_unpad_tiles_for_any_world_size(world, H, W, C):
+    """The ragged half of mi_nerf_all_gather_tiles without RCCL: a staging buffer as the padded in-place all-gather leaves it for `world`
+    ranks (NaN in the padding) -> the frame, bit for bit; float4 and scalar forms."""
+    from nerf_pytorch_paeng_amd import dist as mdist
+    dev = torch.device("cuda:0")
+    frame = torch.rand(H * W, C, generator=torch.Generator(device=dev).manual_seed(world * H), device=dev)
+    max_rows = H // world + (1 if H % world else 0)
+    staging = torch.full((world, max_rows * W * C), float("nan"), device=dev)
+    for r in range(world):
+        r0, nr = mdist.shard_rows(H, world, r)
+        staging[r, :nr * W * C] = frame[r0 * W:(r0 + nr) * W].reshape(-1)
+    got = mdist.unpad_tiles(staging, world, H, W, C)
+    assert torch.equal(got, frame)
+    assert int(_lib_staging_bytes(world, H, W, C)) == (0 if H % world == 0 else staging.numel() * 4)
+
+
+def _lib_staging_bytes(world, H, W, C):
+    from nerf_pytorch_paeng_amd._lib import lib
+    return lib().mi_nerf_all_gather_staging_bytes(world, H, W, C)
+
+
 @pytest.mark.timeout(900)
 def test_bench_one_rank_through_rccl():
     """`python bench.py` with BENCH_FORCE_DIST=1: the worker's RCCL set-up, barriers and max-over-ranks all-reduce at world size 1."""
@@ -138,6 +226,16 @@ def test_bench_collective_block_through_rccl_with_one_rank():
     assert c["backend"] == "nccl" and c["world_size"] == 1 and c["distinct_devices"] == 1 and c["ranks"][0]["cus"] == 256
     assert c["frame_equal_across_ranks"] is True and c["neighbour_tile_recomputed_equal"] is True
     assert 0 < c["all_gather_ms"] < 50 and c["all_gather_bytes_assembled"] == 800 * 800 * 16
+    # the same tile through the C ABI's own communicator (mi_nerf_all_gather_tiles), timed beside it and bit-equal
+    assert c["tile_gather_route"] == "torch" and "error" not in c["c_abi"], c["c_abi"]
+    assert c["c_abi"]["equal_to_torch_route_on_every_rank"] is True and 0 < c["c_abi"]["all_gather_ms"] < 50 and c["c_abi"]["world_size"] == 1
+    # ... and as the route of the timed frames themselves
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--frames", "1", "--train-steps", "0",
+                        "--no-cpu-baseline", "--no-small-batch", "--no-bf16-leg", "--no-f16s-leg"], env=dict(env, BENCH_TILE_GATHER="c_abi"),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line2 = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line2["collective"]["tile_gather_route"] == "c_abi" and line2["frame_checksum"] == line["frame_checksum"]
 
 
 @pytest.mark.timeout(900)
