@@ -146,8 +146,8 @@ int mi_nerf_mlp_rays_bf16_shape(const mi_nerf_net* net, const void* packed_bf16_
 /* SPLIT-PRECISION variant of the fused entry: fp32-grade results on the f16 matrix pipe (gfx950 has no xf32 / TF32; its f32-input MFMA
  * runs at 1/16 of the f16 rate).  Weights and activations travel as f16 pairs x = hi + lo * 2^-11, a product is three
  * v_mfma_f32_16x16x32_f16 with fp32 accumulation (hi.hi, hi.lo, lo.hi; the dropped lo.lo term is 2^-22 of the product): the error
- * against an fp64 evaluation is that of the fp32 kernel.  W = 256; |weights| and |activations| must stay below the f16 maximum
- * (65 504).  Range contract: the host packer refuses larger weights (the device packer counts them: out_of_range_dev below); an
+ * against an fp64 evaluation is that of the fp32 kernel.  W = 256; |weights| and |activations| must stay STRICTLY below the f16 maximum
+ * (65 504; both packers refuse / count |w| >= 65 504 and NaN).  Range contract: the host packer refuses larger weights (the device packer counts them: out_of_range_dev below); an
  * ACTIVATION at or beyond 65 520 comes out as NaN in every output that depends on it -- all four raw values of the point for a trunk
  * unit, the three colours for a linear_feat / linear_d unit -- never as a finite value (the kernels' ReLU is the NaN-propagating
  * maximum); a pre-activation <= -65 520 in front of a ReLU is exact (the unit is off, as in fp32).  An extra precision mode like the

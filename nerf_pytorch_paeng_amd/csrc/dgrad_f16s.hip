@@ -59,7 +59,7 @@ __device__ __forceinline__ void delta_store(const DPair& e0, const DPair& e1, fl
     dmax = __builtin_fmaxf(dmax, __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(e0.y0), __builtin_fabsf(e0.y1)), __builtin_fmaxf(__builtin_fabsf(e1.y0), __builtin_fabsf(e1.y1))));
     f32x4 v;
     v[0] = e0.y0 * inv_s; v[1] = e0.y1 * inv_s; v[2] = e1.y0 * inv_s; v[3] = e1.y1 * inv_s;
-    asm volatile("global_store_dwordx4 %0, %1, off offset:%2 " MN_F16S_STOREFLAGS "\n\ts_nop 1" ::"v"(rowp), "v"(v), "n"(MT * T * 4) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off offset:%2 " F16S_STASH_STORE_FLAGS "\n\ts_nop 1" ::"v"(rowp), "v"(v), "n"(MT * T * 4) : "memory");
 }
 // the 24-slot schedule of pack_sched, with the row piece in the free sixth slot of a tile's second pair
 template <int VAR, int SET, int T, int KS, int SUB>

@@ -51,11 +51,10 @@
 #include "common.h"
 #include "layout.h"
 
-#ifndef MN_BF16_PF_T
-#define MN_BF16_PF_T 3
-#define MN_BF16_PF_KS 2
-#endif
 namespace minerf {
+
+// where the next unit's inputs are requested in the view-direction layer: (job, k-step)
+constexpr int BF16_PF_T = 3, BF16_PF_KS = 2;
 
 typedef unsigned u32x4b __attribute__((ext_vector_type(4)));
 
@@ -65,11 +64,7 @@ typedef unsigned u32x4b __attribute__((ext_vector_type(4)));
 // passes on 256 CUs become 256 + 768 half-size ones).  NP is a template parameter of everything below.
 constexpr int MT = 16;                                     // output features per job
 constexpr int KF = 32;                                     // k per MFMA
-#ifdef MN_BF16_DA
-constexpr int DA = MN_BF16_DA;                             // A/B variant (tools/ab_probe.py)
-#else
 constexpr int DA = 4;                                      // A-operand pipeline depth (fragments in flight)
-#endif
 constexpr int BSLOT_QUADS = 32;
 constexpr int BSLOT_BYTES = BSLOT_QUADS * QUAD_BYTES;      // 32 KiB
 constexpr int BNSLOT = 3;
@@ -365,9 +360,6 @@ __device__ __forceinline__ void bdma16(const char* gaddr_lane) {
 // 4 KiB halves, M0 set twice) or 4 KiB (8 waves)
 template <int NWV>
 __device__ __forceinline__ void bring_dma(const BRing& r, int i) {
-#ifdef MN_BF16_NODMA                                          // ablation builds (timing experiments only, results are garbage)
-    return;
-#endif
     const char* g = r.sbase + r.fetch_off + r.voff + (i >= 4 ? 4096 : 0);
     if (i == 0) bdma_set_m0(r.fetch_lds);
     if (i == 4) bdma_set_m0(r.fetch_lds + 4096);
@@ -390,9 +382,7 @@ template <int NWV>
 __device__ __forceinline__ void bring_advance(BRing& r) {
     if constexpr (NWV == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-#ifndef MN_BF16_NOBARRIER
     __syncthreads();
-#endif
     bring_next_fetch(r);
     r.read_slot = (r.read_slot + 1 == BNSLOT) ? 0 : r.read_slot + 1;
 }
@@ -462,9 +452,6 @@ __device__ __forceinline__ void mfma_acc(f32x4& acc, const u32x4b& afrag, const 
 // MFMA leaves room for two VALU issues), or as one statement where there are more gaps than work.
 template <bool RELU, int R, int STAGE>
 __device__ __forceinline__ void pack_stage(const f32x4& acc, unsigned (&t)[2]) {
-#ifdef MN_BF16_NOPACK
-    return;
-#endif
     if constexpr (STAGE == 0) asm volatile("v_cvt_pk_bf16_f32 %0, %2, %3\n\tv_cvt_pk_bf16_f32 %1, %4, %5" : "=&v"(t[0]), "=&v"(t[1]) : "v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]));
     else if constexpr (STAGE == 1) { if (RELU) asm volatile("v_pk_max_i16 %0, %0, 0\n\tv_pk_max_i16 %1, %1, 0" : "+v"(t[0]), "+v"(t[1])); }
     else asm volatile("v_accvgpr_write_b32 a[%2], %0\n\tv_accvgpr_write_b32 a[%3], %1" ::"v"(t[0]), "v"(t[1]), "n"(R), "n"(R + 1));
@@ -852,7 +839,7 @@ __device__ __forceinline__ void run_phase(const MlpArgsB& a, const PhaseB ph, ch
                     // next pair's rays and depths, two quads BEHIND a ring advance (tail position 162 = slot 5, quad 2): an advance waits for every
                     // older vector memory operation, and two quads before one (position 158, where this sat) is the worst place for a load.  A/B: 0.2 %;
                     // the loads and their index arithmetic cost the kernel 2 % in all (ablation build without them).
-                    if constexpr (t == MN_BF16_PF_T && ks == MN_BF16_PF_KS && p == 1) load_inputs(it + 1 < ph.n_iter ? it + 1 : it);
+                    if constexpr (t == BF16_PF_T && ks == BF16_PF_KS && p == 1) load_inputs(it + 1 < ph.n_iter ? it + 1 : it);
                     if constexpr (ks == 5) {
                         if constexpr (t + 1 < NT / 2) cnextd[p] = *(const f32x4*)(scratch + (p >> 1) * (W / 2) + MT * (t + 1) + 4 * q4);
                         else if constexpr (p == 1) {                    // colour tile: rows 0..2 = colour bias (lane quarter 0 only)
@@ -1056,14 +1043,10 @@ int mlp_rays_bf16(const mi_nerf_net* net, const void* packed_dev, const float* r
     a.o_bias_trunk = L.bias_trunk; a.o_bias_feat = L.bias_feat; a.o_bias_d = L.bias_d; a.o_head_b = L.head_b; a.o_wdir_t = L.wdir_t;
     if (points_per_wave == 64) return launch_bf16<4, 0, 4>(a, n_wtiles, n_wtiles, st);
     if (points_per_wave == 32) return launch_bf16<2, 0, 4>(a, n_wtiles, n_wtiles, st);
-#ifdef MN_BF16_NWV8        // A/B variant build only (python -m nerf_pytorch_paeng_amd.build --variant nwv8 -DMN_BF16_NWV8; tools/bf16_shape_probe.py):
-    // 8 waves of 32 points per workgroup, two waves per SIMD.  Measured SLOWER than the 64-point shape at every size (4096 rays: fine
-    // launch 638 vs 603 us, profiles/r03_bf16_two_waves_per_simd.txt): the kernel is not short of latency hiding, it is short of
-    // power -- twice the LDS reads per FLOP cost more clock than the interleaving wins back.  Not instantiated in the shipped library.
-    if (points_per_wave == 832) return launch_bf16<2, 0, 8>(a, n_wtiles, n_wtiles, st);
-#else
-    MN_CHECK_ARG(points_per_wave != 832, "the 8-wave shape (832) exists in -DMN_BF16_NWV8 variant builds only");
-#endif
+    // (An 8-wave shape -- 32 points per wave, two waves per SIMD -- was measured SLOWER than the 64-point shape at every size: 4096 rays, fine
+    // launch 638 vs 603 us, profiles/r03_bf16_two_waves_per_simd.txt.  The kernel is not short of latency hiding, it is short of power: twice
+    // the LDS reads per FLOP cost more clock than the interleaving wins back.  Its instantiation is gone: tools/ABLATIONS.md.)
+    MN_CHECK_ARG(points_per_wave != 832, "the 8-wave shape (832) was an experiment and is not built (tools/ABLATIONS.md)");
     // The launch plan.  A pass of the 64-point shape takes the same time whatever the number of active CUs (the kernel is bound by
     // what ONE CU does per pass), a pass of the 32-point shape ~0.65 of it (half the matrix work, the same weight stream:
     // profiles/r03_bf16_small_launch_shape.txt).  So: whole rounds of the 64-point shape (every wave of the chip a pair of tiles),

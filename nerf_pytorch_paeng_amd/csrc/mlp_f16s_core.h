@@ -9,12 +9,9 @@
 #include "layout.h"
 
 // where the next unit's inputs are requested in the view-direction layer (job, k-step): behind a ring advance (pair 161 of the tail = slot 10, quad 2)
-#ifndef MN_F16S_PF_T
-#define MN_F16S_PF_T 3
-#define MN_F16S_PF_KS 1
-#endif
 namespace minerf {
 namespace f16s {
+constexpr int PF_T = 3, PF_KS = 1;
 
 typedef unsigned u32x4b __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2b __attribute__((ext_vector_type(2)));
@@ -105,9 +102,6 @@ __device__ __forceinline__ void dma16(const char* gaddr_lane) {
     asm volatile("global_load_lds_dwordx4 %0, off offset:%1" ::"v"(gaddr_lane), "i"(IMM) : "memory");
 }
 __device__ __forceinline__ void ring_dma(const Ring& r, int i) {
-#ifdef MN_F16S_NODMA                                          // ablation builds (timing experiments only, results are garbage)
-    return;
-#endif
     const char* g = r.sbase + r.fetch_off + r.voff + (i >= 4 ? 4096 : 0);
     if (i == 0) set_m0(r.fetch_lds);
     if (i == 4) set_m0(r.fetch_lds + 4096);
@@ -180,18 +174,10 @@ __device__ __forceinline__ void pack_stage(const float h0, const float h1, const
     if constexpr (STAGE == 0) asm volatile("v_fma_f32 %0, %2, %6, %3\n\tv_fma_f32 %1, %4, %6, %5" : "=&v"(t.y0), "=&v"(t.y1) : "v"(l0), "v"(h0), "v"(l1), "v"(h1), "s"(dn));
     else if constexpr (STAGE == 1) asm volatile("v_fma_f32 %0, %2, %6, %3\n\tv_fma_f32 %1, %4, %6, %5" : "=&v"(t.Y0), "=&v"(t.Y1) : "v"(h0), "v"(l0), "v"(h1), "v"(l1), "s"(up));
     else if constexpr (STAGE == 2) {
-#ifdef MN_F16S_MAXNUM_RELU                                     // timing builds only (A/B of the NaN-propagating ReLU): the pre-round-4 instructions
-        if (RELU) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2\n\tv_pk_max_f16 %0, %0, 0" : "=&v"(t.hi) : "v"(t.y0), "v"(t.y1));
-#else
         if (RELU) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2\n\tv_pk_maximum3_f16 %0, %0, 0, 0" : "=&v"(t.hi) : "v"(t.y0), "v"(t.y1));
-#endif
         else asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=&v"(t.hi) : "v"(t.y0), "v"(t.y1));
     } else if constexpr (STAGE == 3) {
-#ifdef MN_F16S_MAXNUM_RELU
-        if (RELU) asm volatile("v_max_f32 %0, %0, 0\n\tv_max_f32 %1, %1, 0" : "+v"(t.Y0), "+v"(t.Y1));
-#else
         if (RELU) asm volatile("v_maximum3_f32 %0, %0, 0, 0\n\tv_maximum3_f32 %1, %1, 0, 0" : "+v"(t.Y0), "+v"(t.Y1));
-#endif
     } else if constexpr (STAGE == 4) {
         // lo halves: f16((y - hi) * 2^11) = f16(fma(hi, -2^11, Y)): the residual is exact, rounded once.  mixlo writes bits 15:0 of the
         // destination, mixhi bits 31:16 (each keeps the other half): the pair lands packed.
@@ -229,9 +215,7 @@ __device__ __forceinline__ void pack_pair_block(const f32x4 (&ph)[NP], const f32
 // f >> 6 (mlp_core.h mask_pack_chunk).  Here lane (q4, col) of point tile p holds f = 16 T + 4 q4 + i: hh = q4 & 1, word T >> 2, nibble
 // (2 T + (q4 >> 1)) & 7 counted from the top.  Lanes q4 and q4 ^ 2 (lane ^ 32) fill alternate nibbles of the same words: the layer's
 // words are OR-ed across that pair once, at the end (finish_masks).
-#ifndef MN_F16S_STOREFLAGS
-#define MN_F16S_STOREFLAGS "nt sc1"
-#endif
+#define F16S_STASH_STORE_FLAGS "nt sc1"
 template <bool RELU, bool MASK, int T>
 __device__ __forceinline__ void stash_tile(const PairTmp& e0, const PairTmp& e1, float* rowp, unsigned (&mw)[4], unsigned nib_sh) {
     f32x4 v;
@@ -245,7 +229,7 @@ __device__ __forceinline__ void stash_tile(const PairTmp& e0, const PairTmp& e1,
     // allocates a line per 64-byte piece); A/B on one box: default 3.62 ms, nt 2.98, nt sc1 2.84, sc1 4.02, sc0 sc1 4.13, no stores 2.21
     // (an asm statement: hipcc does not see a store here, so the wait states it would put between a 128-bit store and a VALU write of
     // the data registers are ours to add -- without them the next instruction's result went to memory instead of the activation)
-    asm volatile("global_store_dwordx4 %0, %1, off offset:%2 " MN_F16S_STOREFLAGS "\n\ts_nop 1" ::"v"(rowp), "v"(v), "n"(MT * T * 4) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off offset:%2 " F16S_STASH_STORE_FLAGS "\n\ts_nop 1" ::"v"(rowp), "v"(v), "n"(MT * T * 4) : "memory");
     if constexpr (MASK) {
         unsigned b[4];
 #pragma unroll
@@ -644,7 +628,7 @@ void mlp_f16s_kernel(const Args a) {
                     }
                     if constexpr (t == 0 && ks == 7 && sub >= 4)            // the density tile finished >= 40 MFMAs ago: keep its one useful value
                         asm volatile("v_fma_f32 %0, %1, %3, %2" : "=v"(dens[sub - 4]) : "v"(hdl[sub - 4][3]), "v"(hdh[sub - 4][3]), "s"(dn));
-                    if constexpr (t == MN_F16S_PF_T && ks == MN_F16S_PF_KS && sub == 3) load_inputs(it + 1 < a.n_iter ? it + 1 : it);      // next unit's ray and depths
+                    if constexpr (t == PF_T && ks == PF_KS && sub == 3) load_inputs(it + 1 < a.n_iter ? it + 1 : it);      // next unit's ray and depths
                     if constexpr (ks == 7 && sub == 2) {
                         if constexpr (t + 1 < NT / 2) { cnextd[0] = *(const f32x4*)(scratch + MT * (t + 1) + 4 * q4); cnextd[1] = cnextd[0]; }
                         else {                                          // colour tile: rows 0..2 = colour bias (lane quarter 0 only)
@@ -672,7 +656,7 @@ void mlp_f16s_kernel(const Args a) {
             // the MFMAs are asm statements: hipcc does not know that the colour tile is still in flight (XDL write -> VALU read), nor that
             // the tiles' fourth registers, which nothing reads, are still to be WRITTEN: the whole tuples pass through the wait statement
             // (keep_tuple, common.h), and nothing else sits between the job and it
-            asm volatile("s_nop 15\n\ts_nop 15" : "+v"(hcl[0]), "+v"(hcl[1]) : "v"(hch[0][3]), "v"(hch[1][3]) : "memory");
+            asm volatile("s_nop 15\n\ts_nop 15" : "+v"(hcl[0]), "+v"(hcl[1]), "+v"(hch[0]), "+v"(hch[1]) : : "memory");
             // (behind the colour tile's window, not inside it: until round 4 a shuffle result landed in a tile's unread fourth register)
             if constexpr (STASH) finish_masks<2>(mw, a.mask_g + (size_t)tile_cur * 128, col, q4, tile_active);
 #pragma unroll

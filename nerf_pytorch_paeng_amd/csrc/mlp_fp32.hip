@@ -97,16 +97,8 @@ void mlp_fp32_kernel(const MlpArgs a) {
     constexpr int KDE = pe_ksteps(LD);  // 16
     constexpr int IN_D = 3 + 6 * LD;
     // groups (t) of a k-quad that carry the training hooks: ReLU' bits, their merge, the row store
-#if defined(MN_HK_B)
-    constexpr int HK_B = MN_HK_B, HK_M = MN_HK_M, HK_S = MN_HK_S;          // A/B variant
-#else
     constexpr int HK_B = NT - 3, HK_M = NT - 2, HK_S = NT - 1;
-#endif
-#ifdef MN_AL_INF
-    constexpr int AL = STASH ? 8 : MN_AL_INF;   // A/B variant (tools/ab_probe.py)
-#else
     constexpr int AL = STASH ? 8 : 4;         // ring_advance<ALLOW>: the training forward interleaves row stores with the DMAs
-#endif
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* side = (float*)(smem + RING_BYTES);
     const int tid = threadIdx.x;
@@ -387,14 +379,10 @@ static int launch(const MlpArgs& args_in, long long n_wtiles, hipStream_t st) {
     const int grid = (int)(n_wg < (long long)num_cus() ? n_wg : (long long)num_cus());
     {   // the tile walk (see the kernel): ray-major once every wave of the grid gets at least one whole ray
         const long long NW = (long long)grid * 4;
-#ifdef MN_NO_RAY_MAJOR
-        args.ray_major = 0;                                  // A/B variant (tools/ab_probe.py)
-#else
         // ... and dealing whole rays does not cost a round more than dealing tiles (1500 rays x 6 tiles on 1024 waves: 12 steps
         // ray-major, 9 tile-major)
         const long long it_ray = (args.n_rays + NW - 1) / NW * args.tpr, it_flat = (n_wg + grid - 1) / grid;
         args.ray_major = (MODE == 0 && args.n_rays >= NW && it_ray <= it_flat) ? 1 : 0;
-#endif
         if (args.ray_major) {
             args.walk_ray = 0; args.walk_chunk = 1; args.walk_carry = NW;
             args.n_iter = (args.n_rays + NW - 1) / NW * args.tpr;

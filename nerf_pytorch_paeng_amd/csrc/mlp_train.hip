@@ -235,18 +235,13 @@ void wgrad_big_kernel(const WgradArgs a) {
     // each 4 MiB L2 at once, and the rows the two waves of a pair share get evicted between their two reads (FETCH_SIZE 18.4 GB
     // per fine-net batch for 14.1 GB of operands).  Ids that share an XCD (v % 8) are laid out consecutively instead, so an
     // L2 sees at most two products: 15.7 GB at the same speed.  (A barrier per three groups brings it to 14.1 GB, every operand
-    // read once, but costs 0.17 % of the step: MN_WG_SYNC, not shipped.)
-#ifndef MN_WG_LINEAR
+    // read once, but costs 0.17 % of the step: not shipped, tools/ABLATIONS.md.)
     const unsigned nwg = gridDim.x * gridDim.y, v = blockIdx.y * gridDim.x + blockIdx.x;
     const unsigned xcd = v & 7, slot = v >> 3;
     const unsigned full = nwg >> 3, rem = nwg & 7;               // XCDs 0..rem-1 host full + 1 workgroups, the others full
     const unsigned flat = xcd * full + (xcd < rem ? xcd : rem) + slot;
     const int b = (int)(flat / gridDim.x);                       // product of the batch
     const unsigned slice = flat - (unsigned)b * gridDim.x;
-#else
-    const int b = blockIdx.y;
-    const unsigned slice = blockIdx.x;
-#endif
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = wm * 128, n0 = wn * 128;
     const bool aok = m0 + 4 * i < a.M[b], bok = n0 + 4 * i < a.N[b];
@@ -318,9 +313,6 @@ void wgrad_big_kernel(const WgradArgs a) {
     auto loop = [&](auto PAR) __attribute__((always_inline)) {
         long long g = 0;
         do {
-#ifdef MN_WG_SYNC                                            // A/B variant: a barrier per three groups
-            __builtin_amdgcn_s_barrier();
-#endif
             step(PAR, ca, cb, fa, fb);
             step(PAR, na, nb, ca, cb);
             step(PAR, fa, fb, na, nb);
@@ -410,11 +402,7 @@ __device__ __forceinline__ void wgrad_f16s_body(const WgradArgs& a, const unsign
     const unsigned slice = flat - (unsigned)b * gridDim.x;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = wm * 128, n0 = wn * 128;
-#ifdef MN_WGF_NODUP                                            // timing build only (results are garbage): every operand row fetched by ONE of the two waves that
-    const bool aok = m0 + 4 * i < a.M[b] && wn == 0, bok = n0 + 4 * i < a.N[b] && wm == 0;      // need it -- the upper bound of what sharing it through LDS could save
-#else
     const bool aok = m0 + 4 * i < a.M[b], bok = n0 + 4 * i < a.N[b];
-#endif
     const float* abase = a.dlt[b];
     const float* bbase = a.x[b];
     const long long ldd = a.ldd[b], ldx = a.ldx[b];
@@ -496,11 +484,9 @@ __device__ __forceinline__ void wgrad_f16s_body(const WgradArgs& a, const unsign
     const long long all_groups = (a.P + GROUP - 1) / GROUP;
     const long long n_groups = (all_groups + slices - 1) / slices;       // per workgroup; surplus groups multiply zeros
     for (long long g = 0; g < n_groups; ++g) {
-#ifdef MN_WGF_SYNC
-        // A/B (not shipped): the waves of a workgroup fetch each row twice between them; a barrier per group keeps the second fetch in the
-        // L2 (FETCH_SIZE 19.7 GB per fine-net batch for 14.1 GB of operands without it) but costs more than it saves: step 13.09 -> 13.58 ms
-        __builtin_amdgcn_s_barrier();
-#endif
+        // (the waves of a workgroup fetch each row twice between them: FETCH_SIZE 19.7 GB per fine-net batch for 14.1 GB of operands.  A barrier
+        // per group keeps the second fetch in the L2 but costs more than it saves -- step 13.09 -> 13.58 ms; fetching each row once bounds the
+        // gain at 13 % of this kernel: profiles/r04_wgrad_f16s_nodup_bound.txt.  Both experiments are closed: tools/ABLATIONS.md.)
         open_group();                                                    // the NEXT group's rows: every unit is requested a whole group ahead
         convert(0, u0); request(0, u0);
         convert(1, u1); request(1, u1);
@@ -993,6 +979,8 @@ int mlp_backward_fp32(const mi_nerf_net* net, const void* packed_fwd, const void
             MN_CHECK_ARG(net->D >= 1 && net->D <= 16 && (net->W == 128 || net->W == 256), "unsupported network D=%d W=%d", net->D, net->W);
             MN_HIP(hipMemsetAsync(grads, 0, (size_t)make_param_offsets(net->D, net->W, net->skip, net->L_x, net->L_d).total * 4, st));
         }
+        if ((mode & 3) && work && work_bytes >= L.work_bytes)      // ... and the split-precision range words say "nothing seen", not whatever the allocator left there
+            MN_HIP(hipMemsetAsync((char*)work + L.partial + al256(WGRAD_PARTIAL_FLOATS * 4), 0, 8, st));
         return MI_NERF_OK;
     }
     MN_CHECK_ARG(packed_fwd && packed_bwd && (x_dev || (rays && z)) && d_raw && stash && work && grads, "NULL device pointer");

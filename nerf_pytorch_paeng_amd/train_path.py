@@ -29,9 +29,13 @@ MAX_TRAIN_RAYS = 16384
 # The split-precision backward runs on d_raw * s with ~256x of f16 headroom (FP16_OVFL: conversions clip at 65504, never inf), and the
 # split-precision packers cannot represent a weight beyond the f16 range: both failure modes are silent on the device.  Every f16s backward
 # folds what it saw into three device words of the model's state (no host synchronisation); they are READ -- one device -> host copy -- on
-# the first such backward and then every F16S_CHECK_EVERY-th, and a saturated chain or an unrepresentable weight then raises (or warns, by
-# F16S_ON_SATURATION).  f16s_status(model) reads them on demand; harness.train() returns them in its dict.
+# after the LAST backward launch of the first F16S_CHECK_FIRST training steps (a step = one _RenderTrain.backward: the coarse and the fine net's
+# launches together, so the fine net's words are in the first read) and then every F16S_CHECK_EVERY-th step, and a saturated chain or an
+# unrepresentable weight then raises (or warns, by F16S_ON_SATURATION).  By the time a later read raises, up to F16S_CHECK_EVERY - 1
+# optimizer.step() calls have already applied clipped gradients: the message says so.  f16s_status(model) reads the words on demand (without
+# resetting them unless asked); harness.train() returns them in its dict.
 F16S_CHECK_EVERY = 50
+F16S_CHECK_FIRST = 3
 F16S_ON_SATURATION = "raise"          # or "warn"
 F16_MAX = 65504.0
 
@@ -49,7 +53,8 @@ class _TrainState:
         self._map_f16s = None
         self.f16s_out_of_range = None          # device counter: weights the split-precision packer could not represent (NaN / beyond f16)
         self.f16s_range = None                 # device [2]: running max of (max |d_raw|, max |delta * s|) over the f16s backwards since the last read
-        self.f16s_backwards = 0                # f16s backward launches so far (host count; sets the read cadence)
+        self.f16s_steps = 0                    # f16s training steps (backward passes) so far (host count; sets the read cadence)
+        self.f16s_steps_since_read = 0
 
     def map_f16s(self) -> torch.Tensor:
         """Gather map of the split-precision blob, built on first use (f16s=True training forward)."""
@@ -61,11 +66,16 @@ class _TrainState:
         return self._map_f16s
 
     def note_f16s_backward(self, work: torch.Tensor, n_rays: int, S: int) -> None:
-        """Fold the range words the split-precision backward left in ``work`` into the running maximum (device side), and at the cadence
-        read them and complain."""
+        """Fold the range words the split-precision backward left in ``work`` into the running maximum (device side; no host sync)."""
+        if n_rays == 0:
+            return                                 # an empty slab launches nothing: there are no words to fold
         torch.maximum(self.f16s_range, ops.backward_range_words(self.net, n_rays, S, work), out=self.f16s_range)
-        self.f16s_backwards += 1
-        if self.f16s_backwards == 1 or self.f16s_backwards % max(1, int(F16S_CHECK_EVERY)) == 0:
+
+    def end_f16s_step(self) -> None:
+        """After the last backward launch of a training step: at the cadence, read the words and complain."""
+        self.f16s_steps += 1
+        self.f16s_steps_since_read += 1
+        if self.f16s_steps <= int(F16S_CHECK_FIRST) or self.f16s_steps % max(1, int(F16S_CHECK_EVERY)) == 0:
             self.check_f16s()
 
     def read_f16s(self, reset: bool = True) -> Dict[str, float]:
@@ -76,15 +86,18 @@ class _TrainState:
         if reset:
             self.f16s_range.zero_()
             self.f16s_out_of_range.zero_()
+            self.f16s_steps_since_read = 0
         d, ds, oor = float(both[0]), float(both[1]), int(both[2])
         return {"max_abs_d_raw": d, "max_abs_delta_scaled": ds, "weights_out_of_range": oor, "saturated": bool(ds >= F16_MAX or ds != ds or oor > 0)}
 
     def check_f16s(self) -> Dict[str, float]:
+        steps = self.f16s_steps_since_read
         r = self.read_f16s()
         if r["saturated"]:
             msg = (f"split-precision training step out of range: max |delta * s| = {r['max_abs_delta_scaled']:.4g} (f16 max {F16_MAX:.0f}; max |d_raw| = "
-                   f"{r['max_abs_d_raw']:.4g}), {r['weights_out_of_range']} weight(s) beyond the f16 range, over up to {F16S_CHECK_EVERY} backward launches: "
-                   f"their gradients were clipped.  Train with the fp32 backward (precision 'fp32') or scale the loss down.")
+                   f"{r['max_abs_d_raw']:.4g}), {r['weights_out_of_range']} weight(s) beyond the f16 range, within the last {steps} training step(s) "
+                   f"(this one included): their gradients were clipped, and the optimizer has already applied up to {max(0, steps - 1)} of them.  "
+                   f"Train with the fp32 backward (precision 'fp32') or scale the loss down.")
             if F16S_ON_SATURATION == "warn":
                 import warnings
                 warnings.warn(msg, RuntimeWarning, stacklevel=3)
@@ -195,6 +208,8 @@ class _RenderTrain(torch.autograd.Function):
 
         gc = one(*saved[1:6], g_rgb_c)
         gf = one(*saved[6:11], g_rgb_f) if ctx.Nf > 0 else [None] * len(st.names)
+        if ctx.f16s and net.W == 256 and (g_rgb_c is not None or g_rgb_f is not None):
+            st.end_f16s_step()                                 # both nets' range words are folded: read them at the cadence
         return (None, None, None, None, None, None, *gc, *gf)
 
 
@@ -261,8 +276,8 @@ def render_train(rays: torch.Tensor, model: torch.nn.Module, opts, *, t_rand=Non
 def f16s_status(model: torch.nn.Module, reset: bool = True) -> Dict[str, float]:
     """What the split-precision training steps of ``model`` saw since the last read (one device -> host copy): max |d_raw|, max |delta * s|
     (how much of the f16 range the scaled backward chain used; >= 65504 means a conversion saturated and gradients were clipped), the number
-    of weights the split-precision packers could not represent, and ``saturated``.  The training path itself reads these on the first f16s
-    backward and every F16S_CHECK_EVERY-th after it, and raises / warns; this is the on-demand read."""
+    of weights the split-precision packers could not represent, and ``saturated``.  The training path itself reads these after each of the first
+    F16S_CHECK_FIRST f16s steps and every F16S_CHECK_EVERY-th after them, and raises / warns; this is the on-demand read."""
     st = _states.get(model)
     if st is None:
         return {"max_abs_d_raw": 0.0, "max_abs_delta_scaled": 0.0, "weights_out_of_range": 0, "saturated": False}

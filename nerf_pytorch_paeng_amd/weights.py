@@ -64,6 +64,7 @@ class PackedNeRF:
         self._f16s: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
         self._sd = None
         self._flat: Optional[Tuple[torch.Tensor, torch.Tensor]] = None      # device-resident flat parameter vectors (nn.Module source)
+        self.f16s_out_of_range: Optional[torch.Tensor] = None               # device int32 [1], set by the device-side f16s packer
 
     @property
     def device(self) -> torch.device:
@@ -105,14 +106,18 @@ class PackedNeRF:
         vectors when this PackedNeRF came from an nn.Module (like bf16(): packed_for() makes a new one per call, so a host round trip
         here would be a synchronisation per render call), on the host from the kept state dict otherwise (once; the host packer refuses
         weights beyond the f16 range outright).  The device packer cannot refuse: it counts such weights into ``f16s_out_of_range``
-        (a device int32), which ``check_f16s_range()`` reads."""
+        (a device int32), which ``check_f16s_range()`` reads -- here, once, right after the pack launches (a 4-byte device -> host read
+        per packing, i.e. per no-grad render call on an nn.Module; a frozen PackedNeRF pays it once): EVERY caller of the split-precision
+        mode gets the refusal the host packer gives, not a NaN frame."""
         if self._f16s is None:
             if self._flat is not None:
                 key = (tuple(getattr(self.net, f) for f, _ in Net._fields_), str(self.device))
                 if key not in _maps_f16s:
                     _maps_f16s[key] = ops.pack_map_f16s(self.net).to(self.device)
                 self.f16s_out_of_range = torch.zeros(1, dtype=torch.int32, device=self.device)
-                self._f16s = tuple(ops.pack_apply_f16s(self.net, _maps_f16s[key], flat, self.f16s_out_of_range) for flat in self._flat)
+                blobs = tuple(ops.pack_apply_f16s(self.net, _maps_f16s[key], flat, self.f16s_out_of_range) for flat in self._flat)
+                self.check_f16s_range()
+                self._f16s = blobs
             else:
                 if self._sd is None:
                     raise MiNerfError("f16-split packing needs the state dict (keep_state=True)")
@@ -122,9 +127,8 @@ class PackedNeRF:
 
     def check_f16s_range(self) -> int:
         """Weights the device-side split-precision packer could not represent (NaN or beyond the f16 range) -- one device -> host read;
-        raises when there are any.  The eval harness calls it once per test() / render() call, not per frame."""
-        cnt = getattr(self, "f16s_out_of_range", None)
-        n = 0 if cnt is None else int(cnt.item())
+        raises when there are any.  f16s() calls it when it packs on the device; a caller may repeat it."""
+        n = 0 if self.f16s_out_of_range is None else int(self.f16s_out_of_range.item())
         if n:
             raise MiNerfError(f"{n} weight(s) are NaN or beyond the f16 range (65504): the split-precision variant cannot carry this network; use precision 'fp32'")
         return n

@@ -126,7 +126,7 @@ def test_f16s_forward_out_of_range_is_never_a_finite_colour(stash, lego_rays):
 def test_module_source_f16s_blobs_are_packed_on_the_device(lego_rays):
     """packed_for(nn.Module).f16s() builds the split-precision blobs on the device from the flat parameter vectors (no host round trip per
     render call): bit-identical to the host packer's blobs; a weight beyond the f16 range, which the host packer refuses, is COUNTED by the
-    device packer and raised by check_f16s_range() -- the eval harness (opts.precision = "f16s") calls it once per test() / render()."""
+    device packer and raised by check_f16s_range(), which f16s() itself calls once per packing: the harness, render_rays and batchify all refuse."""
     from nerf_pytorch_paeng_amd import harness
     from nerf_pytorch_paeng_amd.model import NeRF, get_positional_encoder
     from nerf_pytorch_paeng_amd.weights import packed_for
@@ -141,9 +141,13 @@ def test_module_source_f16s_blobs_are_packed_on_the_device(lego_rays):
     with torch.no_grad():
         model.model_fine.linear_x[2].weight[3, 5] = 1.0e6
     bad = packed_for(model)
-    bad.f16s()
     with pytest.raises(MiNerfError, match="beyond the f16 range"):
-        bad.check_f16s_range()
+        bad.f16s()                                                   # the refusal the host packer gives, at packing time
+    # ... so EVERY no-grad caller with an nn.Module gets it (round 4: only the eval harness checked; render_rays rendered NaN frames)
+    with torch.no_grad(), pytest.raises(MiNerfError, match="beyond the f16 range"):
+        NP.render_rays(lego_rays[:64].contiguous(), model, None, make_opts(), seed=1, f16s=True)
+    with torch.no_grad(), pytest.raises(MiNerfError, match="beyond the f16 range"):
+        NP.batchify_rays_and_render_by_chunk(lego_rays[:64, :3], lego_rays[:64, 3:], model, None, 8, 8, np.eye(3), make_opts(), seed=1, f16s=True)
     K, H, W = synthetic.lego_camera()
     opts = make_opts(precision="f16s", exp_name="x")
     pose = torch.as_tensor(synthetic.pose_spherical(0.0, -30.0, 4.0), dtype=torch.float32)
@@ -454,7 +458,7 @@ def test_f16s_backward_gradient_range(gain, exact, n, S, lego_rays):
 
 def test_training_path_notices_a_saturated_f16s_backward(lego_rays, monkeypatch):
     """A 4000x amplification inside the backward chain, through the TRAINING path (render_train -> loss.backward()): the step reads the range words the
-    split-precision backward left behind on the first such backward (and every F16S_CHECK_EVERY-th after it) and raises; in "warn" mode it
+    split-precision backward left behind after each of the first F16S_CHECK_FIRST steps (and every F16S_CHECK_EVERY-th after them) and raises; in "warn" mode it
     warns and f16s_status() reports the numbers; a well-scaled network passes with the scaled chain inside the f16 range."""
     import warnings
     from types import SimpleNamespace
@@ -486,21 +490,33 @@ def test_training_path_notices_a_saturated_f16s_backward(lego_rays, monkeypatch)
         return m
 
     good = make(16.0)
+    monkeypatch.setattr(train_path, "F16S_CHECK_FIRST", 0)                         # leave the words for the on-demand read
+    monkeypatch.setattr(train_path, "F16S_CHECK_EVERY", 1000)
     step(good)
     st = train_path.f16s_status(good)
     assert not st["saturated"] and 128.0 <= st["max_abs_delta_scaled"] < 65504.0 and st["weights_out_of_range"] == 0, st
     assert all(torch.isfinite(p.grad).all() for p in good.parameters())
 
+    # the default cadence: the words are read after BOTH nets' backward launches of each of the first F16S_CHECK_FIRST steps -- the very first
+    # step raises, before any optimizer.step() has applied a clipped gradient (the message counts the steps already applied)
+    monkeypatch.setattr(train_path, "F16S_CHECK_FIRST", 3)
+    monkeypatch.setattr(train_path, "F16S_CHECK_EVERY", 50)
     bad = make(4000.0)
-    with pytest.raises((MiNerfError, RuntimeError), match="split-precision training step out of range"):
+    with pytest.raises((MiNerfError, RuntimeError), match=r"split-precision training step out of range.*within the last 1 training step.*applied up to 0 of them"):
         step(bad)
+    # only the FINE net amplifies: its words are in the first read too (until round 5 the first read came after the coarse launch alone)
+    fine_only = make(4000.0)
+    fine_only.model_coarse.load_state_dict(make(16.0).model_coarse.state_dict())
+    with pytest.raises((MiNerfError, RuntimeError), match="split-precision training step out of range"):
+        step(fine_only)
     monkeypatch.setattr(train_path, "F16S_ON_SATURATION", "warn")
     bad2 = make(4000.0)
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
         step(bad2)
     assert any("out of range" in str(x.message) for x in w)
-    # the cadence: the next F16S_CHECK_EVERY - 2 backwards are not read, f16s_status reads on demand
+    # the cadence: behind the first F16S_CHECK_FIRST steps only every F16S_CHECK_EVERY-th is read; f16s_status reads on demand
+    monkeypatch.setattr(train_path, "F16S_CHECK_FIRST", 1)
     monkeypatch.setattr(train_path, "F16S_CHECK_EVERY", 1000)
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")

@@ -572,6 +572,15 @@ def test_empty_batch_backward_is_zero_not_uninitialised_memory():
     grads, _ = ops.mlp_backward(net, packed, packed_bwd, rays, z, d_raw, stash, grads=poison)
     assert grads.data_ptr() == poison.data_ptr() and torch.count_nonzero(poison).item() == 0
     assert ops.mlp_backward(net, packed, packed_bwd, rays, z, d_raw, stash, stage=1)[0] is None      # deltas only: no gradient vector to mistake for one
+    # split-precision backward over an empty slab: the two range words the training path folds into its saturation monitor read "nothing
+    # seen", not the allocator's leftovers (NaN here), and the training path does not fold them at all
+    net256 = ops.make_net(4, 256, 1)
+    sd256 = synthetic.make_state_dict(5, 4, 256, skips=(1,))
+    p256, pb256 = ops.pack_module(sd256, "model_fine.", net256).to(DEV), ops.pack_module(sd256, "model_fine.", net256, backward=True).to(DEV)
+    _, stash256 = ops.mlp_rays_train(net256, p256, rays, z)
+    work = torch.full((ops.train_layout(net256, 0, S).work_bytes,), 0xFF, dtype=torch.uint8, device=DEV)
+    g256, _ = ops.mlp_backward(net256, p256, pb256, rays, z, d_raw, stash256, work=work, f16s_wgrad=True)
+    assert torch.count_nonzero(g256).item() == 0 and ops.backward_range(net256, 0, S, work) == (0.0, 0.0)
     x = torch.empty(0, 90, device=DEV)
     out, st = ops.mlp_embedded_train(net, packed, x)
     poison.fill_(float("nan"))

@@ -286,6 +286,83 @@ def test_mfma_destinations_and_c_operands_are_left_alone_for_their_wait_states(s
     assert seen > min_mfma
 
 
+# Pairs per kernel that are inside their window when an intervening MFMA is priced at ONE wait state (what LLVM's recogniser assumes) and
+# outside it at the pipe's ISSUE INTERVAL (P / 2 = 4 wait states for the 16x16x32 f16 / bf16 shapes: tools/mfma_probe.hip measured one
+# 8-pass MFMA per 16 clocks per wave, which is also what the 2.5 PFLOP/s peak is made of): the reliance of the asm kernels' schedules on
+# the matrix pipe's rate, as of hipcc 7.2 / round 5.  The in-order wave cannot issue the instruction behind an MFMA earlier than that
+# interval, so these are safe; but the NUMBER must not grow silently with a compiler change -- it is pinned here.
+STRICT_RELIANCE = {
+    ("mlp_bf16.hip", "mlp_bf16_kernelILi256ELi10ELi4ELi4ELi0ELi4E"): 4,
+    ("mlp_bf16.hip", "mlp_bf16_kernelILi256ELi10ELi4ELi2ELi0ELi4E"): 195,
+    ("mlp_bf16.hip", "mlp_bf16_kernelILi256ELi10ELi4ELi4ELi2ELi4E"): 199,
+    ("mlp_f16s.hip", "mlp_f16s_kernelILb0E"): 74,
+    ("mlp_f16s_stash.hip", "mlp_f16s_kernelILb1E"): 13,
+    ("dgrad_f16s.hip", "dgrad_f16s_kernel"): 54,
+}
+
+
+@pytest.mark.parametrize("src", ["mlp_bf16.hip", "mlp_f16s.hip", "mlp_f16s_stash.hip", "dgrad_f16s.hip", "mlp_fp32.hip", "mlp_train.hip"])
+def test_reliance_on_the_mfma_issue_interval_does_not_grow(src, capsys):
+    """`mfma_hazard_check.py --strict` per kernel: printed, and bounded by today's counts (builtin-MFMA kernels: zero -- hipcc pads those itself)."""
+    import os
+    import sys
+    from nerf_pytorch_paeng_amd import build
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import mfma_hazard_check as H
+    if not os.path.exists(H.OBJDUMP):
+        pytest.skip("llvm-objdump not found")
+    seen = set()
+    for name, ins in H.kernels_of(H.device_asm(build.ensure_object(src))).items():
+        n, bad = H.check(ins, strict=True)
+        if n == 0:
+            continue
+        keys = [k for k in STRICT_RELIANCE if k[0] == src and k[1] in name]
+        limit = STRICT_RELIANCE[keys[0]] if keys else 0
+        seen.update(keys)
+        with capsys.disabled():
+            print(f"\n  strict  {src}  {name[:84]}: {n} MFMAs, {len(bad)} pairs rely on the issue interval (pinned: {limit})")
+            for b in sorted(bad, key=lambda x: int(x.split("+")[1].split("ws")[0]))[:3]:
+                print("      ", b[:200])
+        assert len(bad) <= limit, f"{name}: {len(bad)} pairs rely on the MFMA issue interval, {limit} when this was pinned; worst: {bad[:3]}"
+    assert seen == {k for k in STRICT_RELIANCE if k[0] == src}, (src, seen)          # every pinned kernel is still in the object
+
+
+def test_hazard_checker_skips_host_only_objects():
+    import os
+    import sys
+    from nerf_pytorch_paeng_amd import build
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import mfma_hazard_check as H
+    if not os.path.exists(H.OBJDUMP):
+        pytest.skip("llvm-objdump not found")
+    obj = build.ensure_object("pack.cpp")
+    assert H.device_asm(obj) == "" and H.main(["x", obj]) == 0
+
+
+def test_no_ablation_switches_in_the_shipped_sources():
+    """Round 3's only GPU fault came from an A/B build of the kernel sources.  The timing switches are gone (tools/ABLATIONS.md): the shipped
+    flags define no MN_* macro, and every MN_* conditional left in csrc/ (today: MN_DIAG) is named by a script under tools/ that builds it."""
+    import os
+    import re
+    from nerf_pytorch_paeng_amd import build
+    flags = [*build.FLAGS, *[f for v in build.FILE_FLAGS.values() for f in v]]
+    assert not [f for f in flags if f.startswith("-DMN_")], flags
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tools_text = "".join(open(os.path.join(root, "tools", f), errors="ignore").read() for f in os.listdir(os.path.join(root, "tools"))
+                         if f.endswith((".py", ".sh")))
+    build_text = open(os.path.join(root, "nerf_pytorch_paeng_amd", "build.py")).read()
+    conds, n_if = set(), 0
+    for f in sorted(os.listdir(build.CSRC)):
+        for line in open(os.path.join(build.CSRC, f)):
+            if re.match(r"\s*#\s*(if|ifdef|ifndef|elif)\b", line):
+                n_if += 1
+                conds.update(re.findall(r"MN_[A-Z0-9_]+", line))
+    assert conds == {"MN_DIAG"}, conds
+    for c in conds:
+        assert f"-D{c}" in tools_text + build_text, c
+    assert n_if <= 14, n_if                                           # 12 MN_DIAG sites today (30 conditionals before the prune)
+
+
 def test_mfma_hazard_checker_sees_a_planted_hazard():
     """The checker on hand-made listings: the NOPACK build's two faulting patterns, a load-return write, a clean stream."""
     import os

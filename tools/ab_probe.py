@@ -1,7 +1,7 @@
 """A/B timing of the fused MLP kernel: the shipped library against a variant built with
 `python -m nerf_pytorch_paeng_amd.build --variant TAG -D...`, alternating in ONE process on ONE box (box-to-box
 variance is ~0.5 %, more than most single changes):  python tools/ab_probe.py TAG[,TAG2,...] [rounds] [bf16] [points_per_wave] [rays] [S]
-A TAG may carry its defines, `nodma:-DMN_F16S_NODMA`: variants live in build_scratch/, which does not travel to the GPU box, so a missing one is
+A TAG may carry its defines, `diag:-DMN_DIAG` (the timing switches of rounds 2-4 are gone from the sources: tools/ABLATIONS.md): variants live in build_scratch/, which does not travel to the GPU box, so a missing one is
 built where the probe runs (~1.5 min of box time each)."""
 import ctypes as C
 import os

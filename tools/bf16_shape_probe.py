@@ -15,7 +15,7 @@ blobs = packed.bf16()
 K, H, W = synthetic.lego_camera()
 pose = synthetic.pose_spherical(0.0, -30.0, 4.0)
 rays_list = [int(a) for a in sys.argv[1:]] or [128, 256, 384, 512, 768, 1024, 2048, 4096]
-SHAPES = (64, 32, 832, 0) if os.environ.get("MI_NERF_LIB", "").endswith("nwv8.so") else (64, 32, 0)      # 832: -DMN_BF16_NWV8 variant builds
+SHAPES = (64, 32, 0)          # (an 8-wave shape, 832, was measured and dropped: tools/ABLATIONS.md)
 ROUNDS = 5
 for n in rays_list:
     pix = torch.from_numpy(synthetic.pixel_batch(H, W, n, 0)).to(dev)
