@@ -38,6 +38,16 @@ __host__ __device__ constexpr int pe_ksteps(int L) { return ((3 * L + 2 + 3) / 4
 // kernel evaluates the full encoding, the extra products add exact zeros.  More frequencies than 10 / 4 are refused.
 constexpr int KERNEL_LX = 10, KERNEL_LD = 4;
 
+// The same for the WIDTH (opts.netWidth, config.py:57).  The fp32 inference kernels are instantiated for W = 128 and W = 256; a network of any
+// other width 2 <= W <= 256 runs on the next instantiated one: the packer lays the blob out for kernel_width(W) and gives the hidden units the
+// network does not have zero weights and zero biases.  Such a unit is exactly 0 before and after its ReLU and multiplies zero weights in the
+// next layer, so the real units' sums gain exact zeros in places where the k order leaves the real terms' order alone: the result is the
+// W-wide network's, at the padded width's cost.  (W / 2, the width of linear_d, is W // 2 as in model/NeRF.py:28.)  The training kernels,
+// the bf16 and the split-precision variants take their native widths only.
+constexpr int MAX_KERNEL_WIDTH = 256;
+__host__ __device__ constexpr int kernel_width(int W) { return W <= 128 ? 128 : 256; }
+__host__ __device__ constexpr bool native_width(int W) { return W == 128 || W == 256; }
+
 struct BlobLayout {
     // all byte offsets from the blob start
     uint32_t stream_off;          // == HEADER_BYTES
@@ -60,8 +70,9 @@ struct BlobLayout {
 __host__ __device__ inline uint32_t round_up_u32(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
 
 // elem_bytes: 4 (fp32 stream) or 2 (bf16 stream; quads keep 1 KiB, see mlp_bf16.hip)
-inline BlobLayout make_layout(int D, int W, int skip, int /*L_x*/, int /*L_d*/) {
-    constexpr int L_x = KERNEL_LX, L_d = KERNEL_LD;              // the layout is the kernels', whatever the network's own L (see above)
+inline BlobLayout make_layout(int D, int W_net, int skip, int /*L_x*/, int /*L_d*/) {
+    constexpr int L_x = KERNEL_LX, L_d = KERNEL_LD;              // the layout is the kernels', whatever the network's own L and W (see above)
+    const int W = kernel_width(W_net);
     BlobLayout b{};
     const int NT = W / 32;
     const int in_d = 3 + 6 * L_d;

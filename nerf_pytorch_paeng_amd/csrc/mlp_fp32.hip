@@ -357,7 +357,7 @@ void mlp_fp32_kernel(const MlpArgs a) {
 // ---------------------------------------------------------------------------------------------
 static int check_net(const mi_nerf_net* net) {
     MN_CHECK_ARG(net != nullptr, "net is NULL");
-    MN_CHECK_ARG(net->W == 256 || net->W == 128, "unsupported width W=%d (kernels exist for 128 and 256)", net->W);
+    MN_CHECK_ARG(net->W >= 2 && net->W <= MAX_KERNEL_WIDTH, "unsupported width W=%d (the fp32 inference kernels run 2 <= W <= %d, padded to 128 / 256)", net->W, MAX_KERNEL_WIDTH);
     MN_CHECK_ARG(net->D >= 2 && net->D <= 16, "unsupported depth D=%d", net->D);
     MN_CHECK_ARG(net->L_x >= 0 && net->L_x <= KERNEL_LX && net->L_d >= 0 && net->L_d <= KERNEL_LD,
                  "unsupported encoding L_x=%d L_d=%d (the kernels evaluate up to %d / %d frequencies)", net->L_x, net->L_d, KERNEL_LX, KERNEL_LD);
@@ -456,7 +456,7 @@ int mlp_rays_fp32(const mi_nerf_net* net, const void* packed_dev, const float* r
     fill_common(a, net, packed_dev, false);
     a.rays = rays_dev; a.z = z_dev; a.out = raw_dev; a.S = S; a.tpr = (S + 31) / 32;
     a.n_wtiles = (long long)n_rays * a.tpr; a.n_rays = n_rays;
-    return net->W == 256 ? launch<256, 0>(a, a.n_wtiles, st) : launch<128, 0>(a, a.n_wtiles, st);
+    return kernel_width(net->W) == 256 ? launch<256, 0>(a, a.n_wtiles, st) : launch<128, 0>(a, a.n_wtiles, st);
 }
 
 // training forward: same kernel, additionally keeping every layer's activations row-major for the backward pass
@@ -464,6 +464,7 @@ int mlp_rays_fp32_stash(const mi_nerf_net* net, const void* packed_dev, const fl
                         int64_t n_rays, int S, float* raw_dev, float* stash_h, float* stash_f, float* stash_g, unsigned* mask_h,
                         unsigned* mask_g, hipStream_t st) {
     if (int rc = check_net(net)) return rc;
+    MN_CHECK_ARG(native_width(net->W), "the training kernels exist for W = 128 and 256 (got %d)", net->W);
     MN_CHECK_ARG(n_rays >= 0 && S >= 1, "bad sizes n_rays=%lld S=%d", (long long)n_rays, S);
     if (n_rays == 0) return MI_NERF_OK;
     MN_CHECK_ARG(packed_dev && rays_dev && z_dev && raw_dev && stash_h && stash_f && stash_g && mask_h && mask_g, "NULL device pointer");
@@ -481,6 +482,7 @@ int mlp_rays_fp32_stash(const mi_nerf_net* net, const void* packed_dev, const fl
 int mlp_embedded_fp32_stash(const mi_nerf_net* net, const void* packed_dev, const float* x_dev, int64_t n, float* out_dev, float* stash_h,
                             float* stash_f, float* stash_g, unsigned* mask_h, unsigned* mask_g, hipStream_t st) {
     if (int rc = check_net(net)) return rc;
+    MN_CHECK_ARG(native_width(net->W), "the training kernels exist for W = 128 and 256 (got %d)", net->W);
     MN_CHECK_ARG(n >= 0, "bad n=%lld", (long long)n);
     if (n == 0) return MI_NERF_OK;
     MN_CHECK_ARG(packed_dev && x_dev && out_dev && stash_h && stash_f && stash_g && mask_h && mask_g, "NULL device pointer");
@@ -503,7 +505,7 @@ int mlp_embedded_fp32(const mi_nerf_net* net, const void* packed_dev, const floa
     fill_common(a, net, packed_dev, true);
     a.x = x_dev; a.out = out_dev; a.n_pts = n;
     a.n_wtiles = (n + 31) / 32;
-    return net->W == 256 ? launch<256, 1>(a, a.n_wtiles, st) : launch<128, 1>(a, a.n_wtiles, st);
+    return kernel_width(net->W) == 256 ? launch<256, 1>(a, a.n_wtiles, st) : launch<128, 1>(a, a.n_wtiles, st);
 }
 
 }  // namespace minerf

@@ -788,7 +788,7 @@ constexpr size_t WGRAD_PARTIAL_FLOATS = (size_t)256 * 256 * 256 + (size_t)256 * 
 
 int train_layout(const mi_nerf_net* net, int64_t n_rays, int S, mi_nerf_train_layout* L) {
     MN_CHECK_ARG(net && L, "NULL net/layout");
-    MN_CHECK_ARG(net->W == 256 || net->W == 128, "unsupported width W=%d", net->W);
+    MN_CHECK_ARG(native_width(net->W), "the training kernels exist for W = 128 and 256 (got %d; inference pads narrower networks)", net->W);
     MN_CHECK_ARG(net->D >= 2 && net->D <= 16, "unsupported depth D=%d", net->D);
     MN_CHECK_ARG(n_rays >= 0 && S >= 1, "bad sizes n_rays=%lld S=%d", (long long)n_rays, S);
     const size_t p = (size_t)n_rays * S, W = (size_t)net->W, D = (size_t)net->D;

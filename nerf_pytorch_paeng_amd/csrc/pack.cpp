@@ -30,13 +30,15 @@ std::vector<KStep> enc_ksteps(int LK, int L, int base) {
     return ks;
 }
 
-// k-steps over a W-wide activation held in accumulator layout, columns [base, base+W)
-std::vector<KStep> act_ksteps(int W, int base) {
+// k-steps over a W-wide activation held in accumulator layout, columns [base, base+W); of those only the first n_real exist in the
+// network (narrower than the kernel: layout.h kernel_width) -- the others are the padded units, whose weights are zero
+std::vector<KStep> act_ksteps(int W, int base, int n_real = -1) {
+    if (n_real < 0) n_real = W;
     std::vector<KStep> ks;
     for (int t = 0; t < W / 32; ++t)
         for (int r = 0; r < 16; ++r) {
             const int f = 32 * t + (r & 3) + 8 * (r >> 2);
-            ks.push_back({base + f, base + f + 4});
+            ks.push_back({f < n_real ? base + f : -1, f + 4 < n_real ? base + f + 4 : -1});
         }
     return ks;
 }
@@ -80,50 +82,60 @@ void emit_part_t(std::vector<float>& stream, const float* Wm, int n_rows, int ld
 }  // namespace
 
 int pack_fp32(const mi_nerf_net* net, const mi_nerf_params* p, void* blob, size_t blob_bytes) {
-    const int D = net->D, W = net->W, NT = W / 32;
+    // Wn: the network's width (the parameter tensors' shapes, model/NeRF.py:24-30); W: the width of the kernel that will run it (layout.h
+    // kernel_width: hidden units Wn .. W-1 get zero weights and biases); Hn / W/2 likewise for linear_d's W // 2 outputs
+    MN_CHECK_ARG(net->W >= 2 && net->W <= MAX_KERNEL_WIDTH, "unsupported width W=%d (the fp32 inference kernels run 2 <= W <= %d)", net->W, MAX_KERNEL_WIDTH);
+    const int D = net->D, Wn = net->W, Hn = Wn / 2, W = kernel_width(Wn), NT = W / 32;
     const int in_x = 3 + 6 * net->L_x, in_d = 3 + 6 * net->L_d;
-    const BlobLayout L = make_layout(D, W, net->skip, net->L_x, net->L_d);
+    const BlobLayout L = make_layout(D, Wn, net->skip, net->L_x, net->L_d);
     MN_CHECK_ARG(blob_bytes >= L.total_bytes, "blob too small: %zu < %u", blob_bytes, L.total_bytes);
     memset(blob, 0, L.total_bytes);
 
     std::vector<float> stream;
     stream.reserve(L.stream_bytes_full / 4);
-    emit_part(stream, p->linear_x_w[0], W, in_x, NT, enc_ksteps(KERNEL_LX, net->L_x, 0));
+    emit_part(stream, p->linear_x_w[0], Wn, in_x, NT, enc_ksteps(KERNEL_LX, net->L_x, 0));
     for (int l = 1; l < D; ++l) {
         const bool cat = (net->skip >= 0 && l == net->skip + 1);
-        const int n_in = cat ? W + in_x : W;
-        if (cat) emit_part(stream, p->linear_x_w[l], W, n_in, NT, enc_ksteps(KERNEL_LX, net->L_x, 0));   // [gamma(x), h]
-        emit_part(stream, p->linear_x_w[l], W, n_in, NT, act_ksteps(W, cat ? in_x : 0));
+        const int n_in = cat ? Wn + in_x : Wn;
+        if (cat) emit_part(stream, p->linear_x_w[l], Wn, n_in, NT, enc_ksteps(KERNEL_LX, net->L_x, 0));   // [gamma(x), h]
+        emit_part(stream, p->linear_x_w[l], Wn, n_in, NT, act_ksteps(W, cat ? in_x : 0, Wn));
     }
-    emit_part(stream, p->linear_feat_w, W, W, NT, act_ksteps(W, 0));
-    emit_part(stream, p->linear_d_w, W / 2, W + in_d, NT / 2, act_ksteps(W, 0));                // [feature, gamma(d)]
+    emit_part(stream, p->linear_feat_w, Wn, Wn, NT, act_ksteps(W, 0, Wn));
+    emit_part(stream, p->linear_d_w, Hn, Wn + in_d, NT / 2, act_ksteps(W, 0, Wn));              // [feature, gamma(d)]
     MN_CHECK_ARG(stream.size() * 4 == L.stream_bytes_hoist, "internal: hoisted stream %zu != %u", stream.size() * 4, L.stream_bytes_hoist);
-    emit_part(stream, p->linear_d_w, W / 2, W + in_d, NT / 2, enc_ksteps(KERNEL_LD, net->L_d, W));
+    emit_part(stream, p->linear_d_w, Hn, Wn + in_d, NT / 2, enc_ksteps(KERNEL_LD, net->L_d, Wn));
     MN_CHECK_ARG(stream.size() * 4 == L.stream_bytes_full, "internal: full stream %zu != %u", stream.size() * 4, L.stream_bytes_full);
 
     uint32_t* hdr = (uint32_t*)blob;
-    hdr[0] = BLOB_MAGIC; hdr[1] = 1; hdr[2] = D; hdr[3] = W; hdr[4] = (uint32_t)net->skip; hdr[5] = KERNEL_LX; hdr[6] = KERNEL_LD;   // the LAYOUT's L
-    hdr[13] = net->L_x; hdr[14] = net->L_d;                                                                                            // the network's
+    hdr[0] = BLOB_MAGIC; hdr[1] = 1; hdr[2] = D; hdr[3] = W; hdr[4] = (uint32_t)net->skip; hdr[5] = KERNEL_LX; hdr[6] = KERNEL_LD;   // the LAYOUT's W and L
+    hdr[13] = net->L_x; hdr[14] = net->L_d; hdr[15] = Wn;                                                                              // the network's
     hdr[7] = L.stream_off; hdr[8] = L.stream_bytes_hoist; hdr[9] = L.stream_bytes_full; hdr[10] = L.side_off; hdr[11] = L.side_floats;
     hdr[12] = 4;   // stream element bytes
     memcpy((char*)blob + L.stream_off, stream.data(), L.stream_bytes_full);
 
-    float* side = (float*)((char*)blob + L.side_off);
-    for (int l = 0; l < D; ++l) memcpy(side + L.bias_trunk + (size_t)l * W, p->linear_x_b[l], W * 4);
-    memcpy(side + L.bias_feat, p->linear_feat_b, W * 4);
-    memcpy(side + L.bias_d, p->linear_d_b, (W / 2) * 4);
-    memcpy(side + L.dens_w, p->linear_density_w, W * 4);
+    float* side = (float*)((char*)blob + L.side_off);                  // zero-filled above: the padded units' entries stay zero
+    for (int l = 0; l < D; ++l) memcpy(side + L.bias_trunk + (size_t)l * W, p->linear_x_b[l], Wn * 4);
+    memcpy(side + L.bias_feat, p->linear_feat_b, Wn * 4);
+    memcpy(side + L.bias_d, p->linear_d_b, Hn * 4);
+    memcpy(side + L.dens_w, p->linear_density_w, Wn * 4);
     side[L.dens_b] = p->linear_density_b[0];
-    memcpy(side + L.color_w, p->linear_color_w, 3 * (W / 2) * 4);
+    for (int c = 0; c < 3; ++c) memcpy(side + L.color_w + (size_t)c * (W / 2), p->linear_color_w + (size_t)c * Hn, Hn * 4);
     memcpy(side + L.color_b, p->linear_color_b, 3 * 4);
     for (int f = 0; f < in_d; ++f)
-        for (int n = 0; n < W / 2; ++n) side[L.wdir_t + (size_t)f * (W / 2) + n] = p->linear_d_w[(size_t)n * (W + in_d) + W + f];
+        for (int n = 0; n < Hn; ++n) side[L.wdir_t + (size_t)f * (W / 2) + n] = p->linear_d_w[(size_t)n * (Wn + in_d) + Wn + f];
     return MI_NERF_OK;
 }
 
-size_t packed_bytes_bwd(const mi_nerf_net* net) { return HEADER_BYTES + (size_t)bwd_stream_bytes(net->D, net->W); }
+size_t packed_bytes_bwd(const mi_nerf_net* net) {
+    if (!native_width(net->W)) {
+        set_error("the training kernels exist for W = 128 and 256 (got %d; inference pads narrower networks)", net->W);
+        return 0;
+    }
+    return HEADER_BYTES + (size_t)bwd_stream_bytes(net->D, net->W);
+}
 
 int pack_bwd_fp32(const mi_nerf_net* net, const mi_nerf_params* p, void* blob, size_t blob_bytes) {
+    MN_CHECK_ARG(native_width(net->W), "the training kernels exist for W = 128 and 256 (got %d; inference pads narrower networks)", net->W);
     const int D = net->D, W = net->W, NT = W / 32;
     const int in_x = 3 + 6 * net->L_x, in_d = 3 + 6 * net->L_d;
     const size_t total = packed_bytes_bwd(net);
@@ -153,6 +165,7 @@ int pack_map(const mi_nerf_net* net, int kind, int32_t* map, size_t map_len) {
     const ParamOffsets po = make_param_offsets(D, W, net->skip, net->L_x, net->L_d);
     MN_CHECK_ARG(po.total < (1u << 24), "network too large for the index map (%u parameters)", po.total);
     MN_CHECK_ARG(kind == 0 || kind == 1, "kind must be 0 (forward) or 1 (backward)");
+    MN_CHECK_ARG(kind == 0 || native_width(W), "the training kernels exist for W = 128 and 256 (got %d; inference pads narrower networks)", W);
     const size_t bytes = kind == 0 ? make_layout(D, W, net->skip, net->L_x, net->L_d).total_bytes : packed_bytes_bwd(net);
     MN_CHECK_ARG(map && map_len * 4 >= bytes, "map too small: %zu entries for %zu bytes", map_len, bytes);
     std::vector<float> flat(po.total);

@@ -542,6 +542,54 @@ def test_other_network_shapes(D, W):
     assert err(raw, ref) <= 1e-4
 
 
+@pytest.mark.parametrize("D,W,skip", [(8, 64, 4), (4, 64, 4), (8, 192, 4), (6, 100, 2), (8, 200, 4), (3, 31, 0), (8, 129, 4)])
+def test_network_widths_without_a_kernel_of_their_own(D, W, skip, lego_rays):
+    """--netWidth values the reference accepts (config.py:57; model/NeRF.py:24-30 builds any W) but no kernel is instantiated for: the
+    packer lays such a network out for the next kernel width (64 -> 128, 192 -> 256) with zero weights for the hidden units it does not
+    have (csrc/layout.h kernel_width): the kernels' results are the W-wide network's.  F6-style against the oracle: embedded rows, the fused
+    rays entry, the whole render_rays step, a module model through batchify; training, bf16 and split precision refuse such widths."""
+    from nerf_pytorch_paeng_amd._lib import MiNerfError
+    from nerf_pytorch_paeng_amd.model import NeRF
+    skips = (skip,)
+    sd = synthetic.make_state_dict(40 + W, D, W, skips=skips)
+    packed = weights.PackedNeRF.from_state_dict(sd, DEV)
+    assert (packed.net.D, packed.net.W) == (D, W) and packed.net.skip == (skip if skip + 1 < D else -1)
+    x = torch.rand(333, 90, generator=torch.Generator().manual_seed(W)) * 2 - 1
+    for fine, blob in ((False, packed.coarse), (True, packed.fine)):
+        y = ops.mlp_embedded(packed.net, blob, x.to(DEV))
+        ref = R.mlp_forward(sd, "model_fine." if fine else "model_coarse.", x, D, 63, 27, skips=skips, dtype=torch.float64)
+        assert err(y, ref) <= 5e-5, (fine, err(y, ref))
+    n, S = 70, 96
+    rays = lego_rays[:n].contiguous()
+    z = torch.sort(T(R.counter_uniform(4, 0, 0, n, S)) * 4 + 2, -1)[0]
+    raw = ops.mlp_rays(packed.net, packed.fine, rays, z.to(DEV))
+    ref = R.mlp_forward(sd, "model_fine.", R.embed(rays.cpu(), z, 10, 4).double(), D, 63, 27, skips=skips, dtype=torch.float64).reshape(n, S, 4)
+    assert err(raw, ref) <= 2e-4, err(raw, ref)
+    # the whole step, depths pinned to the oracle's (sample_pdf is discontinuous), through a module model built at this width
+    opts = make_opts()
+    model = NeRF(D, W, 63, 27, skips=[skip]).to(DEV)
+    model.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+    g = torch.Generator().manual_seed(3)
+    t_rand, u = torch.rand(n, 64, generator=g), torch.rand(n, 128, generator=g)
+    cfg = R.PathConfig(netDepth=D, netWidth=W, skips=skips)
+    want = R.render_rays(rays.cpu(), sd, cfg, t_rand, u)
+    with torch.no_grad():
+        got = NP.render_rays(rays, model, None, opts, t_rand=t_rand, u=u)
+        rc, dc, rf, df = NP.batchify_rays_and_render_by_chunk(rays[:, :3], rays[:, 3:], model, None, 8, 8, np.eye(3), opts, t_rand=t_rand, u=u)
+    assert torch.equal(rc, got["rgb_c"]) and torch.equal(rf, got["rgb_f"])
+    assert err(got["rgb_c"], want["rgb_c"]) <= 2e-5 and err(got["disp_c"], want["disp_c"]) <= 2e-5
+    z_f = want["_z_f"].to(DEV)
+    pinned = ops.composite(ops.mlp_rays(packed.net, packed.fine, rays, z_f), z_f, rays)[0]
+    assert err(pinned, want["rgb_f"]) <= 2e-5
+    assert float(((got["rgb_f"].cpu() - want["rgb_f"]).abs().amax(-1) > 1e-4).float().mean()) <= 0.03
+    # what does not pad says so
+    for kw in (dict(bf16=True), dict(f16s=True)):
+        with pytest.raises(MiNerfError):
+            NP.render_rays(rays, packed, None, opts, t_rand=t_rand, u=u, **kw)
+    with pytest.raises((MiNerfError, RuntimeError), match="training kernels exist for W = 128 and 256"):
+        NP.render_rays(rays, model, None, opts, t_rand=t_rand, u=u)["rgb_c"].sum().backward()
+
+
 @pytest.mark.parametrize("W,L_x,L_d", [(256, 6, 2), (256, 10, 0), (256, 0, 4), (128, 4, 4), (128, 8, 1)])
 def test_fewer_encoding_frequencies(W, L_x, L_d, lego_rays):
     """--L_x / --L_d below the defaults (config.py:54-55).  gamma_L is a prefix of gamma_10 in the reference's channel order
@@ -628,7 +676,7 @@ def test_error_behaviour(packed_big, lego_rays):
     with pytest.raises(MiNerfError):
         ops.sample_pdf(torch.rand(4, 8, device=DEV), torch.rand(4, 8, device=DEV), 16, False, None)   # weights must be B-1, u needed
     with pytest.raises(MiNerfError):
-        weights.PackedNeRF.from_state_dict(synthetic.make_state_dict(0, 4, 64), DEV)               # unsupported width
+        weights.PackedNeRF.from_state_dict(synthetic.make_state_dict(0, 4, 320), DEV)              # wider than the widest kernel (narrower ones pad)
     with pytest.raises(MiNerfError):
         NP.render_rays(lego_rays[:4].cpu(), weights.packed_for(packed_big), None, opts, t_rand=torch.rand(4, 63))   # wrong t_rand shape
 

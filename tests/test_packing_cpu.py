@@ -42,8 +42,14 @@ def test_pack_rejects_bad_shapes_and_unsupported_nets():
     bad = dict(sd); bad["model_coarse.linear_feat.weight"] = np.zeros((128, 64), np.float32)
     with pytest.raises(_lib.MiNerfError):
         ops.pack_module(bad, "model_coarse.", net)
-    with pytest.raises(_lib.MiNerfError):
-        ops.pack_module(synthetic.make_state_dict(1, 4, 64), "model_coarse.", ops.make_net(4, 64, -1))
+    with pytest.raises(_lib.MiNerfError, match="unsupported width W=320"):          # wider than the widest kernel: refused, not truncated
+        ops.pack_module(synthetic.make_state_dict(1, 4, 320), "model_coarse.", ops.make_net(4, 320, -1))
+    narrow = synthetic.make_state_dict(1, 4, 64)                                    # narrower: fp32 inference pads (below); the other blobs refuse
+    for kw in (dict(bf16=True), dict(f16s=True), dict(backward=True)):
+        with pytest.raises(_lib.MiNerfError):
+            ops.pack_module(narrow, "model_coarse.", ops.make_net(4, 64, -1), **kw)
+    with pytest.raises(_lib.MiNerfError, match="training kernels exist for W = 128 and 256"):
+        ops.train_layout(ops.make_net(4, 64, -1), 8, 32)
 
 
 def test_cpu_tensors_are_refused():
@@ -51,11 +57,15 @@ def test_cpu_tensors_are_refused():
         ops.stratified_z(2.0, 6.0, torch.rand(4, 64))
 
 
-@pytest.mark.parametrize("D,W", [(8, 256), (4, 128)])
-def test_blob_emulation_matches_oracle_embedded(D, W):
-    sd = synthetic.make_state_dict(11, D, W)
+# widths the reference's --netWidth accepts (config.py:57) but no kernel is instantiated for: packed into the next kernel width with
+# zero weights for the units the network does not have (layout.h kernel_width) -- 64 -> 128, 200 -> 256, odd halves (W // 2), tiny
+@pytest.mark.parametrize("D,W,skip", [(8, 256, 4), (4, 128, 4), (4, 64, 4), (6, 64, 2), (5, 200, 1), (3, 100, 0), (4, 31, 4), (2, 2, -1), (8, 129, 4)])
+def test_blob_emulation_matches_oracle_embedded(D, W, skip):
+    sd = synthetic.make_state_dict(11, D, W, skips=() if skip < 0 else (skip,))
     net = weights.infer_net(sd)
+    assert net.W == W
     blob = ops.pack_module(sd, "model_fine.", net).numpy()
+    assert blob.nbytes == _lib.lib().mi_nerf_packed_bytes(ctypes.byref(ops.make_net(D, 128 if W <= 128 else 256, skip)))      # the padded width's layout
     rs = np.random.RandomState(0)
     x = rs.uniform(-1, 1, size=(32, 90)).astype(np.float32)
     emu = Emu(blob)
@@ -70,12 +80,12 @@ def test_blob_emulation_matches_oracle_embedded(D, W):
         reg[3 * L + 1, :32] = row_block[:, 2]
         return reg
     out = emu.tile(gather(x[:, :63].astype(np.float64), 10), de=gather(x[:, 63:].astype(np.float64), 4))
-    ref = R.mlp_forward(sd, "model_fine.", torch.from_numpy(x), D, 63, 27, dtype=torch.float64).numpy()
+    ref = R.mlp_forward(sd, "model_fine.", torch.from_numpy(x), D, 63, 27, skips=() if skip < 0 else (skip,), dtype=torch.float64).numpy()
     np.testing.assert_allclose(out, ref, atol=1e-9, rtol=1e-9)
 
 
-def test_blob_emulation_matches_oracle_fused():
-    D, W = 8, 256
+@pytest.mark.parametrize("D,W", [(8, 256), (8, 64), (8, 192), (4, 100)])
+def test_blob_emulation_matches_oracle_fused(D, W):
     sd = synthetic.make_state_dict(5, D, W)
     net = weights.infer_net(sd)
     blob = ops.pack_module(sd, "model_coarse.", net).numpy()
