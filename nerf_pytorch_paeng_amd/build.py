@@ -30,7 +30,7 @@ INCLUDE = os.path.join(ROOT, "include")
 SCRATCH = os.path.join(ROOT, "build_scratch")
 LIB = os.path.join(HERE, "libmi_nerf.so")
 STAMP = LIB + ".stamp"
-SOURCES = ["api.hip", "stages.hip", "mlp_fp32.hip", "mlp_bf16.hip", "mlp_f16s.hip", "mlp_f16s_stash.hip", "dgrad_f16s.hip", "mlp_train.hip", "frames.hip", "comm.hip", "pack.cpp"]
+SOURCES = ["api.hip", "stages.hip", "mlp_fp32.hip", "mlp_fp32_wide.hip", "mlp_bf16.hip", "mlp_f16s.hip", "mlp_f16s_stash.hip", "dgrad_f16s.hip", "mlp_train.hip", "frames.hip", "comm.hip", "pack.cpp"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
          # the MLP kernel's register-resident design needs its k-loops FULLY unrolled (static register indices)

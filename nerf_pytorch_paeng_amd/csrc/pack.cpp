@@ -43,6 +43,56 @@ std::vector<KStep> act_ksteps(int W, int base, int n_real = -1) {
     return ks;
 }
 
+// ---- the W16 stream order (mlp_fp32_wide.hip, v_mfma_f32_16x16x4_f32): a k-step feeds four input columns, one per lane quarter -------------
+struct KStep4 { int c[4]; };    // input column fed by lane quarter 0..3; -1 = zero pad
+
+std::vector<KStep4> enc_ksteps16(int LK, int L, int base) {
+    std::vector<KStep4> ks;
+    const int combos = 3 * LK;
+    for (int s = 0; s < (combos + 1) / 2; ++s) {
+        KStep4 k{};
+        for (int q = 0; q < 4; ++q) {
+            const int m = 2 * s + (q >> 1);
+            k.c[q] = (m < combos && m / 3 < L) ? base + 3 + 6 * (m / 3) + (m % 3) + 3 * (q & 1) : -1;
+        }
+        ks.push_back(k);
+    }
+    ks.push_back(KStep4{{base + 0, base + 1, base + 2, -1}});
+    while ((int)ks.size() < pe_ksteps16(LK)) ks.push_back(KStep4{{-1, -1, -1, -1}});
+    return ks;
+}
+
+// a W-wide activation in the 16x16 accumulator layout: register r of output tile t on lane quarter q holds feature 16t + 4q + r, and k-step
+// 4t + r of the next layer multiplies those four
+std::vector<KStep4> act_ksteps16(int W, int base, int n_real) {
+    std::vector<KStep4> ks;
+    for (int t = 0; t < W / 16; ++t)
+        for (int r = 0; r < 4; ++r) {
+            KStep4 k{};
+            for (int q = 0; q < 4; ++q) {
+                const int f = 16 * t + 4 * q + r;
+                k.c[q] = f < n_real ? base + f : -1;
+            }
+            ks.push_back(k);
+        }
+    return ks;
+}
+
+// quad(T, kq): float [64 lanes][4]: lane l = (i = l & 15: output feature 16T + i; quarter l >> 4), element j: k-step 4kq + j
+void emit_part16(std::vector<float>& stream, const float* Wm, int n_out, int n_in, int NT, const std::vector<KStep4>& ks) {
+    const int KQ = (int)ks.size() / 4;
+    for (int kq = 0; kq < KQ; ++kq)
+        for (int T = 0; T < NT; ++T)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 4; ++j) {
+                    const int col = ks[4 * kq + j].c[lane >> 4];
+                    const int n = 16 * T + (lane & 15);
+                    stream.push_back((col >= 0 && n < n_out) ? Wm[(size_t)n * n_in + col] : 0.0f);
+                }
+    const size_t slot_floats = SLOT_BYTES / 4;
+    while (stream.size() % slot_floats) stream.push_back(0.0f);
+}
+
 // Append one GEMM part to the stream: quads in (kq, T) order, padded to a whole number of slots.
 void emit_part(std::vector<float>& stream, const float* Wm, int n_out, int n_in, int NT, const std::vector<KStep>& ks) {
     const int KQ = (int)ks.size() / 4;
@@ -93,6 +143,21 @@ int pack_fp32(const mi_nerf_net* net, const mi_nerf_params* p, void* blob, size_
 
     std::vector<float> stream;
     stream.reserve(L.stream_bytes_full / 4);
+    const bool w16 = W == 512;          // the 512-wide kernel's stream order (same part sizes: a quad is 256 weights in either order)
+    if (w16) {
+        const int NT16 = W / 16;
+        emit_part16(stream, p->linear_x_w[0], Wn, in_x, NT16, enc_ksteps16(KERNEL_LX, net->L_x, 0));
+        for (int l = 1; l < D; ++l) {
+            const bool cat = (net->skip >= 0 && l == net->skip + 1);
+            const int n_in = cat ? Wn + in_x : Wn;
+            if (cat) emit_part16(stream, p->linear_x_w[l], Wn, n_in, NT16, enc_ksteps16(KERNEL_LX, net->L_x, 0));
+            emit_part16(stream, p->linear_x_w[l], Wn, n_in, NT16, act_ksteps16(W, cat ? in_x : 0, Wn));
+        }
+        emit_part16(stream, p->linear_feat_w, Wn, Wn, NT16, act_ksteps16(W, 0, Wn));
+        emit_part16(stream, p->linear_d_w, Hn, Wn + in_d, NT16 / 2, act_ksteps16(W, 0, Wn));
+        MN_CHECK_ARG(stream.size() * 4 == L.stream_bytes_hoist, "internal: hoisted stream %zu != %u", stream.size() * 4, L.stream_bytes_hoist);
+        emit_part16(stream, p->linear_d_w, Hn, Wn + in_d, NT16 / 2, enc_ksteps16(KERNEL_LD, net->L_d, Wn));
+    } else {
     emit_part(stream, p->linear_x_w[0], Wn, in_x, NT, enc_ksteps(KERNEL_LX, net->L_x, 0));
     for (int l = 1; l < D; ++l) {
         const bool cat = (net->skip >= 0 && l == net->skip + 1);
@@ -104,10 +169,11 @@ int pack_fp32(const mi_nerf_net* net, const mi_nerf_params* p, void* blob, size_
     emit_part(stream, p->linear_d_w, Hn, Wn + in_d, NT / 2, act_ksteps(W, 0, Wn));              // [feature, gamma(d)]
     MN_CHECK_ARG(stream.size() * 4 == L.stream_bytes_hoist, "internal: hoisted stream %zu != %u", stream.size() * 4, L.stream_bytes_hoist);
     emit_part(stream, p->linear_d_w, Hn, Wn + in_d, NT / 2, enc_ksteps(KERNEL_LD, net->L_d, Wn));
+    }
     MN_CHECK_ARG(stream.size() * 4 == L.stream_bytes_full, "internal: full stream %zu != %u", stream.size() * 4, L.stream_bytes_full);
 
     uint32_t* hdr = (uint32_t*)blob;
-    hdr[0] = BLOB_MAGIC; hdr[1] = 1; hdr[2] = D; hdr[3] = W; hdr[4] = (uint32_t)net->skip; hdr[5] = KERNEL_LX; hdr[6] = KERNEL_LD;   // the LAYOUT's W and L
+    hdr[0] = BLOB_MAGIC; hdr[1] = w16 ? 6 : 1; hdr[2] = D; hdr[3] = W; hdr[4] = (uint32_t)net->skip; hdr[5] = KERNEL_LX; hdr[6] = KERNEL_LD;   // the LAYOUT's W and L
     hdr[13] = net->L_x; hdr[14] = net->L_d; hdr[15] = Wn;                                                                              // the network's
     hdr[7] = L.stream_off; hdr[8] = L.stream_bytes_hoist; hdr[9] = L.stream_bytes_full; hdr[10] = L.side_off; hdr[11] = L.side_floats;
     hdr[12] = 4;   // stream element bytes

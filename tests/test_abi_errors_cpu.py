@@ -77,7 +77,7 @@ def test_null_net_and_unsupported_shapes_are_refused(name):
     a = _args(name, good, cfg)
     a[list(_lib.SIGNATURES[name][1]).index(_lib._NETP)] = None
     assert getattr(lib, name)(*a) == EINVAL and lib.mi_nerf_last_error()
-    for bad in (ops.make_net(8, 320, 4), ops.make_net(8, 1, 4), ops.make_net(0, 256, -1), ops.make_net(40, 256, 4)):   # widths / depths no kernel can run (2 <= W <= 256 pads)
+    for bad in (ops.make_net(8, 600, 4), ops.make_net(8, 1, 4), ops.make_net(0, 256, -1), ops.make_net(40, 256, 4)):   # widths / depths no kernel can run (2 <= W <= 512 pads)
         b = _args(name, bad, cfg)
         assert getattr(lib, name)(*b) == EINVAL, (name, bad.D, bad.W)
 

@@ -542,18 +542,20 @@ def test_other_network_shapes(D, W):
     assert err(raw, ref) <= 1e-4
 
 
-@pytest.mark.parametrize("D,W,skip", [(8, 64, 4), (4, 64, 4), (8, 192, 4), (6, 100, 2), (8, 200, 4), (3, 31, 0), (8, 129, 4)])
+@pytest.mark.parametrize("D,W,skip", [(8, 64, 4), (4, 64, 4), (8, 192, 4), (6, 100, 2), (8, 200, 4), (3, 31, 0), (8, 129, 4),
+                                      (8, 512, 4), (4, 300, 1), (8, 257, 4), (2, 512, -1), (16, 384, 7)])
 def test_network_widths_without_a_kernel_of_their_own(D, W, skip, lego_rays):
     """--netWidth values the reference accepts (config.py:57; model/NeRF.py:24-30 builds any W) but no kernel is instantiated for: the
-    packer lays such a network out for the next kernel width (64 -> 128, 192 -> 256) with zero weights for the hidden units it does not
-    have (csrc/layout.h kernel_width): the kernels' results are the W-wide network's.  F6-style against the oracle: embedded rows, the fused
+    packer lays such a network out for the next kernel width (64 -> 128, 192 -> 256, 300 -> 512) with zero weights for the hidden units it
+    does not have (csrc/layout.h kernel_width): the kernels' results are the W-wide network's.  Wider than 256 runs on mlp_fp32_wide.hip
+    (16 points per wave on v_mfma_f32_16x16x4_f32; --netWidth 512 itself is a native width of that kernel).  F6-style against the oracle: embedded rows, the fused
     rays entry, the whole render_rays step, a module model through batchify; training, bf16 and split precision refuse such widths."""
     from nerf_pytorch_paeng_amd._lib import MiNerfError
     from nerf_pytorch_paeng_amd.model import NeRF
-    skips = (skip,)
+    skips = (skip,) if skip >= 0 else ()
     sd = synthetic.make_state_dict(40 + W, D, W, skips=skips)
     packed = weights.PackedNeRF.from_state_dict(sd, DEV)
-    assert (packed.net.D, packed.net.W) == (D, W) and packed.net.skip == (skip if skip + 1 < D else -1)
+    assert (packed.net.D, packed.net.W) == (D, W) and packed.net.skip == (skip if 0 <= skip and skip + 1 < D else -1)
     x = torch.rand(333, 90, generator=torch.Generator().manual_seed(W)) * 2 - 1
     for fine, blob in ((False, packed.coarse), (True, packed.fine)):
         y = ops.mlp_embedded(packed.net, blob, x.to(DEV))
@@ -567,7 +569,7 @@ def test_network_widths_without_a_kernel_of_their_own(D, W, skip, lego_rays):
     assert err(raw, ref) <= 2e-4, err(raw, ref)
     # the whole step, depths pinned to the oracle's (sample_pdf is discontinuous), through a module model built at this width
     opts = make_opts()
-    model = NeRF(D, W, 63, 27, skips=[skip]).to(DEV)
+    model = NeRF(D, W, 63, 27, skips=list(skips)).to(DEV)
     model.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
     g = torch.Generator().manual_seed(3)
     t_rand, u = torch.rand(n, 64, generator=g), torch.rand(n, 128, generator=g)
@@ -676,7 +678,7 @@ def test_error_behaviour(packed_big, lego_rays):
     with pytest.raises(MiNerfError):
         ops.sample_pdf(torch.rand(4, 8, device=DEV), torch.rand(4, 8, device=DEV), 16, False, None)   # weights must be B-1, u needed
     with pytest.raises(MiNerfError):
-        weights.PackedNeRF.from_state_dict(synthetic.make_state_dict(0, 4, 320), DEV)              # wider than the widest kernel (narrower ones pad)
+        weights.PackedNeRF.from_state_dict(synthetic.make_state_dict(0, 4, 600), DEV)              # wider than the widest kernel (narrower ones pad)
     with pytest.raises(MiNerfError):
         NP.render_rays(lego_rays[:4].cpu(), weights.packed_for(packed_big), None, opts, t_rand=torch.rand(4, 63))   # wrong t_rand shape
 

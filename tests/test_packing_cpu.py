@@ -42,8 +42,8 @@ def test_pack_rejects_bad_shapes_and_unsupported_nets():
     bad = dict(sd); bad["model_coarse.linear_feat.weight"] = np.zeros((128, 64), np.float32)
     with pytest.raises(_lib.MiNerfError):
         ops.pack_module(bad, "model_coarse.", net)
-    with pytest.raises(_lib.MiNerfError, match="unsupported width W=320"):          # wider than the widest kernel: refused, not truncated
-        ops.pack_module(synthetic.make_state_dict(1, 4, 320), "model_coarse.", ops.make_net(4, 320, -1))
+    with pytest.raises(_lib.MiNerfError, match="unsupported width W=600"):          # wider than the widest kernel: refused, not truncated
+        ops.pack_module(synthetic.make_state_dict(1, 4, 600), "model_coarse.", ops.make_net(4, 600, -1))
     narrow = synthetic.make_state_dict(1, 4, 64)                                    # narrower: fp32 inference pads (below); the other blobs refuse
     for kw in (dict(bf16=True), dict(f16s=True), dict(backward=True)):
         with pytest.raises(_lib.MiNerfError):
@@ -81,6 +81,34 @@ def test_blob_emulation_matches_oracle_embedded(D, W, skip):
         return reg
     out = emu.tile(gather(x[:, :63].astype(np.float64), 10), de=gather(x[:, 63:].astype(np.float64), 4))
     ref = R.mlp_forward(sd, "model_fine.", torch.from_numpy(x), D, 63, 27, skips=() if skip < 0 else (skip,), dtype=torch.float64).numpy()
+    np.testing.assert_allclose(out, ref, atol=1e-9, rtol=1e-9)
+
+
+@pytest.mark.parametrize("D,W,skip", [(3, 512, 0), (2, 300, -1), (4, 257, 1)])
+def test_wide_blob_emulation_matches_oracle(D, W, skip):
+    """Networks wider than 256 (--netWidth 512, config.py:57): packed for the 512-wide kernel in the W16 stream order (mlp_fp32_wide.hip:
+    16 points per wave on v_mfma_f32_16x16x4_f32); tests/blob_emulator.py EmuWide walks the stream as that kernel does.  Embedded mode (the
+    direction k-steps in the stream) and fused mode (hoisted direction bias) against the oracle in fp64."""
+    from tests.blob_emulator import EmuWide
+    skips = () if skip < 0 else (skip,)
+    sd = synthetic.make_state_dict(19, D, W, skips=skips)
+    net = weights.infer_net(sd)
+    blob = ops.pack_module(sd, "model_fine.", net).numpy()
+    assert blob.nbytes == _lib.lib().mi_nerf_packed_bytes(ctypes.byref(ops.make_net(D, 512, skip)))
+    emu = EmuWide(blob)
+    rs = np.random.RandomState(2)
+    x = rs.uniform(-1, 1, size=(16, 90))
+    out = emu.tile(emu.gather_regs(10, x[:, :63]), de=emu.gather_regs(4, x[:, 63:]))
+    ref = R.mlp_forward(sd, "model_fine.", torch.from_numpy(x), D, 63, 27, skips=skips, dtype=torch.float64).numpy()
+    np.testing.assert_allclose(out, ref, atol=1e-9, rtol=1e-9)
+    ray = rs.normal(size=6)
+    z = np.sort(rs.uniform(2, 6, 16))
+    p = ray[:3, None] + ray[3:, None] * z[None, :]
+    v = ray[3:] / np.linalg.norm(ray[3:])
+    g = R.posenc(torch.from_numpy(v[None]), 4)[0].numpy()
+    out = emu.tile(emu.enc_regs(10, p), dir_gamma=g)
+    xx = torch.cat([R.posenc(torch.from_numpy(p.T.copy()), 10), torch.from_numpy(g)[None].expand(16, 27)], -1)
+    ref = R.mlp_forward(sd, "model_fine.", xx, D, 63, 27, skips=skips, dtype=torch.float64).numpy()
     np.testing.assert_allclose(out, ref, atol=1e-9, rtol=1e-9)
 
 
