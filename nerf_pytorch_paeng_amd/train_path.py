@@ -21,7 +21,7 @@ import torch
 
 from . import ops
 from ._lib import MiNerfError, Net, as_f32_dev
-from .weights import _param_shape, infer_net
+from .weights import _param_shape, infer_net, pad_index_map, padded_train_net
 
 # rays per autograd node: the activation stash is ~9.9 KB per sample point (W = 256, D = 8)
 MAX_TRAIN_RAYS = 16384
@@ -45,7 +45,12 @@ class _TrainState:
 
     def __init__(self, model: torch.nn.Module, device: torch.device):
         sd = model.state_dict()
-        self.net: Net = infer_net(sd)
+        # net_model: the module's own shape (model/NeRF.py:24-30); net: what the training kernels run -- the same, or for a width without
+        # training kernels (--netWidth 64, config.py:57) the next wider one, parameters scattered into zeros (weights.pad_index_map)
+        self.net_model: Net = infer_net(sd)
+        self.net: Net = padded_train_net(self.net_model)
+        self.pad_idx = None if self.net is self.net_model else pad_index_map(self.net_model, self.net).to(device)
+        self.n_flat = ops.param_count(self.net)
         self.device = device
         self.names = ops.param_names(self.net)
         self.map_fwd = ops.pack_map(self.net, False).to(device)
@@ -109,6 +114,29 @@ class _TrainState:
         self.map_f16s()
         return self._map_bwd_f16s
 
+    def flat(self, params) -> torch.Tensor:
+        """Flat fp32 parameter vector of the network the kernels run (zero-padded to its width when the module's is narrower)."""
+        f = _flat(params)
+        if self.pad_idx is None:
+            return f
+        wide = torch.zeros(self.n_flat, dtype=torch.float32, device=f.device)
+        wide[self.pad_idx] = f
+        return wide
+
+    def split_grads(self, grads: torch.Tensor) -> List[torch.Tensor]:
+        """The kernels' flat gradient -> one tensor per parameter of the MODULE, in st.names order."""
+        if self.pad_idx is not None:
+            grads = grads[self.pad_idx]
+        out, off = [], 0
+        for k in self.names:
+            shape = _param_shape(self.net_model, k)
+            cnt = 1
+            for s in shape:
+                cnt *= s
+            out.append(grads[off:off + cnt].view(shape))
+            off += cnt
+        return out
+
     def params(self, module: torch.nn.Module) -> List[torch.Tensor]:
         named = dict(module.named_parameters())
         try:
@@ -157,7 +185,7 @@ class _RenderTrain(torch.autograd.Function):
                 return ops.mlp_rays_train(net, ops.pack_apply_f16s(net, st.map_f16s(), flat, st.f16s_out_of_range), rays, z, f16s=True)
             return ops.mlp_rays_train(net, blob, rays, z)
 
-        flat_c = _flat(params[:n_each])
+        flat_c = st.flat(params[:n_each])
         blob_c = ops.pack_apply(st.map_fwd, flat_c)
         z_c = ops.stratified_z(cfg["near"], cfg["far"], t_rand) if z_override is None else z_override[0]
         raw_c, stash_c = forward_net(flat_c, blob_c, z_c)
@@ -165,7 +193,7 @@ class _RenderTrain(torch.autograd.Function):
         ctx.st, ctx.Nf, ctx.f16s = st, Nf, f16s
         saved = [rays, flat_c, blob_c, z_c, raw_c, stash_c]
         if Nf > 0:
-            flat_f = _flat(params[n_each:])
+            flat_f = st.flat(params[n_each:])
             blob_f = ops.pack_apply(st.map_fwd, flat_f)
             z_f = ops.fine_z(z_c, w_c, Nf, det, None if det else u) if (z_override is None or z_override[1] is None) else z_override[1]
             raw_f, stash_f = forward_net(flat_f, blob_f, z_f)
@@ -196,15 +224,7 @@ class _RenderTrain(torch.autograd.Function):
             grads, work = ops.mlp_backward(net, blob, blob_b, rays, z, d_raw, stash, f16s_wgrad=f16s, f16s_dgrad=f16s_dgrad)
             if f16s:
                 st.note_f16s_backward(work, z.shape[0], z.shape[1])
-            out, off = [], 0
-            for k in st.names:
-                shape = _param_shape(net, k)
-                cnt = 1
-                for s in shape:
-                    cnt *= s
-                out.append(grads[off:off + cnt].view(shape))
-                off += cnt
-            return out
+            return st.split_grads(grads)
 
         gc = one(*saved[1:6], g_rgb_c)
         gf = one(*saved[6:11], g_rgb_f) if ctx.Nf > 0 else [None] * len(st.names)
@@ -218,7 +238,7 @@ class _EmbeddedTrain(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, st: _TrainState, x, *params):
-        flat = _flat(params)
+        flat = st.flat(params)
         blob = ops.pack_apply(st.map_fwd, flat)
         out, stash = ops.mlp_embedded_train(st.net, blob, x)
         ctx.st = st
@@ -231,15 +251,7 @@ class _EmbeddedTrain(torch.autograd.Function):
         x, flat, blob, stash = ctx.saved_tensors
         blob_b = ops.pack_apply(st.map_bwd, flat)
         grads = ops.mlp_embedded_backward(st.net, blob, blob_b, x, g_out.contiguous().float(), stash)
-        out, off = [], 0
-        for k in st.names:
-            shape = _param_shape(st.net, k)
-            cnt = 1
-            for sdim in shape:
-                cnt *= sdim
-            out.append(grads[off:off + cnt].view(shape))
-            off += cnt
-        return (None, None, *out)
+        return (None, None, *st.split_grads(grads))
 
 
 def render_train(rays: torch.Tensor, model: torch.nn.Module, opts, *, t_rand=None, u=None, seed: int = 0, ray_offset: int = 0,

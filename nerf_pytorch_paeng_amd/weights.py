@@ -55,6 +55,39 @@ def _param_shape(net: Net, key: str) -> Tuple[int, ...]:
     return (out, fan_in) if kind == "weight" else (out,)
 
 
+def padded_train_net(net: Net) -> Net:
+    """The network the TRAINING kernels run for ``net``: they exist for W = 128 and 256, a narrower network trains as the next of the two with
+    zero weights and biases for the hidden units it does not have (``pad_index_map``)."""
+    if net.W in (128, 256):
+        return net
+    if not 2 <= net.W < 256:
+        raise MiNerfError(f"the training kernels exist for netWidth <= 256 (got {net.W}); wider networks run inference only")
+    return ops.make_net(net.D, 128 if net.W < 128 else 256, net.skip, net.L_x, net.L_d)
+
+
+def pad_index_map(net: Net, wide: Net) -> torch.Tensor:
+    """int64 [param_count(net)]: where each entry of ``net``'s flat parameter vector (module.parameters() order) sits in the flat vector of
+    ``wide`` = the same network at a larger width.  Rows keep their index; so do columns, except linear_d's view-direction block, which
+    follows the (wider) feature block (model/NeRF.py:28,46: cat([feature, gamma(d)])).  Scattering a network's parameters through this map
+    into zeros gives a network that computes the same function: the extra units are exactly 0 through their ReLU.  Their gradients are 0
+    too (ReLU'(0) = 0 on the way in, activation 0 on the way out), so gathering the wide gradient through the same map IS the gradient."""
+    idx, off = [], 0
+    for key in ops.param_names(net):
+        shp, shp_w = _param_shape(net, key), _param_shape(wide, key)
+        if len(shp) == 1:
+            idx.append(off + torch.arange(shp[0]))
+        else:
+            cols = torch.arange(shp[1])
+            if key == "linear_d.weight":
+                cols = torch.where(cols < net.W, cols, cols + (wide.W - net.W))
+            idx.append((off + torch.arange(shp[0])[:, None] * shp_w[1] + cols[None, :]).reshape(-1))
+        n = 1
+        for v in shp_w:
+            n *= v
+        off += n
+    return torch.cat(idx).to(torch.int64)
+
+
 class PackedNeRF:
     """Both networks of a NeRF, packed and resident on one device."""
 

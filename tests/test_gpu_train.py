@@ -216,11 +216,13 @@ def _train_setup(D=8, W=256, n=96, Sc=32, Nf=48, seed=0):
     return sd, model, posenc, opts, o, d, t_rand, u, target, cfg
 
 
-@pytest.mark.parametrize("f16s", [False, True])
-def test_train_step_gradients_match_oracle_autograd(f16s):
-    """``f16s``: the same step with its three MFMA kernels in split precision, same bars."""
+@pytest.mark.parametrize("D,W,f16s", [(8, 256, False), (8, 256, True), (8, 64, False), (6, 100, False), (8, 200, False), (8, 200, True)])
+def test_train_step_gradients_match_oracle_autograd(D, W, f16s):
+    """``f16s``: the same step with its three MFMA kernels in split precision, same bars.  Widths without training kernels of their own
+    (--netWidth 64 / 100 / 200, config.py:57) train as the next wider network, the parameters scattered into zeros and the gradient gathered
+    back (weights.pad_index_map): same bars, per parameter tensor of the MODULE's own shape."""
     from nerf_pytorch_paeng_amd import nerf_process as NP, train_path
-    sd, model, posenc, opts, o, d, t_rand, u, target, cfg = _train_setup()
+    sd, model, posenc, opts, o, d, t_rand, u, target, cfg = _train_setup(D=D, W=W)
     rays = torch.cat([o, d], -1).contiguous()
     # the oracle's coarse depths and OUR fine depths are pinned on both sides: the forward is ill-conditioned in z
     # (1 ulp of z moves raw by up to 5e-4 through the 2^9 frequency) and sample_pdf is discontinuous, neither of which is
@@ -241,11 +243,16 @@ def test_train_step_gradients_match_oracle_autograd(f16s):
     assert not out["disp_c"].requires_grad and not out["disp_f"].requires_grad
     worst = 0.0
     for k, p in model.named_parameters():
-        assert p.grad is not None, k
+        assert p.grad is not None and p.grad.shape == psd[k].grad.shape, k
         e = rel_err(p.grad, psd[k].grad)
         worst = max(worst, e)
         assert e < 1e-4, (k, e)                                      # relative to the largest entry of that gradient
-    print(f"train step{' (split precision)' if f16s else ''}: worst per-tensor gradient error {worst:.2e} (relative to max)")
+    print(f"train step D={D} W={W}{' (split precision)' if f16s else ''}: worst per-tensor gradient error {worst:.2e} (relative to max)")
+    if W not in (128, 256):                                          # ... and an optimizer step on it keeps working (the state is re-padded per step)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+        opt.step()
+        out2 = train_path.render_train(rays, model, opts, t_rand=t_rand, u=u, z_override=(z_c.to(DEV), z_f), f16s=f16s)
+        assert torch.isfinite(out2["rgb_f"]).all() and not torch.equal(out2["rgb_f"], out["rgb_f"])
 
 
 def test_drop_in_training_loop_runs_and_repacks():
@@ -475,6 +482,9 @@ def test_training_path_refuses_what_it_does_not_support():
     cpu_model = type(model)(4, 128, 63, 27)
     with pytest.raises(ops.MiNerfError):
         NP.batchify_rays_and_render_by_chunk(o, d, cpu_model, posenc, H, Wd, K, opts)                 # no CPU fallback
+    wide = type(model)(4, 320, 63, 27).to(DEV)                                                       # inference only beyond netWidth 256
+    with pytest.raises(ops.MiNerfError, match="training kernels exist for netWidth <= 256"):
+        NP.batchify_rays_and_render_by_chunk(o, d, wide, posenc, H, Wd, K, opts)
 
 
 def test_rays_that_require_grad_are_refused():
