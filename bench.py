@@ -188,7 +188,7 @@ def c_abi_gather_leg(dist, mdist, torch, dev, local, full_torch, H, W) -> dict:
             torch.cuda.set_device(dev)
             ok = 1
             try:
-                mdist.TileComm.unique_id()                 # loads librccl (first use) and proves ncclGetUniqueId answers
+                mdist.TileComm.available()                 # loads librccl (first use): no communicator, no bootstrap socket yet
             except Exception as e:                         # noqa: BLE001
                 ok, out["error"] = 0, repr(e)
             flag = torch.tensor([ok], dtype=torch.int32, device=dev)

@@ -341,6 +341,7 @@ int mi_nerf_permute_rows(const float* src_dev, const int64_t* perm_dev, int64_t 
  *   torch.distributed); each rank calls mi_nerf_comm_init_rank with its device current (hipSetDevice) -- collective over all ranks.
  * ---------------------------------------------------------------------------------------------- */
 #define MI_NERF_COMM_ID_BYTES 128
+int mi_nerf_rccl_available(void);            /* MI_NERF_OK when librccl is resolved (loads it on first call); else MI_NERF_ERCCL + the loader's text */
 int mi_nerf_comm_unique_id(void* id_host);
 int mi_nerf_comm_init_rank(const void* id_host, int world, int rank, void** comm_out);
 int mi_nerf_comm_info(void* comm, int* world_out, int* rank_out, int* device_out);      /* any out pointer may be NULL */

@@ -112,6 +112,7 @@ SIGNATURES = {
     "mi_nerf_to8b": (_I, [_P, _I64, _P, _P, _P]),
     "mi_nerf_rays_rgb": (_I, [_I, _I, C.POINTER(_F), _P, _P, _I64, _P, _P]),
     "mi_nerf_permute_rows": (_I, [_P, _P, _I64, _I, _P, _P]),
+    "mi_nerf_rccl_available": (_I, []),
     "mi_nerf_comm_unique_id": (_I, [_P]),
     "mi_nerf_comm_init_rank": (_I, [_P, _I, _I, C.POINTER(_P)]),
     "mi_nerf_comm_info": (_I, [_P, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),

@@ -133,6 +133,11 @@ using namespace minerf;
 
 extern "C" {
 
+int mi_nerf_rccl_available(void) {
+    const Rccl* r = nullptr;
+    return rccl(&r);
+}
+
 int mi_nerf_comm_unique_id(void* id_host) {
     MN_CHECK_ARG(id_host != nullptr, "id_host is NULL");
     const Rccl* r = nullptr;

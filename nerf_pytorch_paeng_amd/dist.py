@@ -60,6 +60,11 @@ class TileComm:
         self._handle = handle
 
     @staticmethod
+    def available() -> None:
+        """Raise unless librccl can be resolved (it is loaded on first use); makes no communicator and no bootstrap socket."""
+        check(lib().mi_nerf_rccl_available(), "mi_nerf_rccl_available")
+
+    @staticmethod
     def unique_id() -> bytes:
         buf = C.create_string_buffer(COMM_ID_BYTES)
         check(lib().mi_nerf_comm_unique_id(buf), "mi_nerf_comm_unique_id")

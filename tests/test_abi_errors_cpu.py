@@ -102,6 +102,10 @@ def test_tile_gather_helpers_refuse_bad_arguments_before_touching_rccl():
     assert lib.mi_nerf_all_gather_staging_bytes(8, 4096, 1, 4) == 0 and lib.mi_nerf_all_gather_staging_bytes(3, 4096, 1, 4) == 3 * 1366 * 16
     assert lib.mi_nerf_all_gather_staging_bytes(0, 8, 8, 4) == 0 and lib.mi_nerf_all_gather_staging_bytes(16, 8, 8, 4) == 0      # refused geometry
     assert lib.mi_nerf_unpad_tiles(fake, 16, 8, 8, 4, fake, None) == EINVAL and b"cannot be split" in lib.mi_nerf_last_error()
+    # librccl itself: resolved at first use (this image has ROCm's under /opt/rocm/lib, and torch's when torch.distributed is loaded); when it
+    # cannot be, the answer is MI_NERF_ERCCL (3) with the loader's text, never a crash -- and nothing above needed it
+    rc = lib.mi_nerf_rccl_available()
+    assert rc in (0, 3) and (rc == 0 or b"RCCL is not available" in lib.mi_nerf_last_error())
 
 
 def test_the_error_text_is_per_thread():

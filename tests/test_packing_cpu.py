@@ -301,7 +301,7 @@ def test_fragment_file_kernels_own_m0_and_the_agpr_file(src, mfma_name, min_mfma
 
 
 @pytest.mark.parametrize("src,min_mfma", [("mlp_bf16.hip", 4000), ("mlp_f16s.hip", 6000), ("mlp_f16s_stash.hip", 6000), ("dgrad_f16s.hip", 3000),
-                                          ("mlp_fp32.hip", 800), ("mlp_train.hip", 60)])
+                                          ("mlp_fp32.hip", 800), ("mlp_fp32_wide.hip", 10000), ("mlp_train.hip", 60)])
 def test_mfma_destinations_and_c_operands_are_left_alone_for_their_wait_states(src, min_mfma):
     """An MFMA written as an asm statement gets none of hipcc's software wait states: nothing may read or write its destination tuple within
     P + 4 wait states of its issue, no VALU may write its C operand within 7 / 13 (ISA guide 4.5; cdna_hip_programming.md 5.7 item 2).  Round 3's
@@ -339,7 +339,7 @@ STRICT_RELIANCE = {
 }
 
 
-@pytest.mark.parametrize("src", ["mlp_bf16.hip", "mlp_f16s.hip", "mlp_f16s_stash.hip", "dgrad_f16s.hip", "mlp_fp32.hip", "mlp_train.hip"])
+@pytest.mark.parametrize("src", ["mlp_bf16.hip", "mlp_f16s.hip", "mlp_f16s_stash.hip", "dgrad_f16s.hip", "mlp_fp32.hip", "mlp_fp32_wide.hip", "mlp_train.hip"])
 def test_reliance_on_the_mfma_issue_interval_does_not_grow(src, capsys):
     """`mfma_hazard_check.py --strict` per kernel: printed, and bounded by today's counts (builtin-MFMA kernels: zero -- hipcc pads those itself)."""
     import os
