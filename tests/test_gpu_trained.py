@@ -8,7 +8,9 @@ this module makes the nearest thing itself: the BASELINE network (D = 8, W = 256
 
 * ``teacher`` -- images of a fixed random 8 x 256 NeRF rendered by the inference kernels (the scene of test_gpu_harness.py), and
 * ``solids``  -- an analytic scene with hard surfaces in front of the white background (a textured sphere, a box, a chequered slab;
-                 ground truth ray-marched in float64 by plain torch), which is what drives a NeRF's weights to lego-like magnitudes,
+                 ground truth ray-marched in float64 by plain torch), which is what drives a NeRF's weights to lego-like magnitudes, and
+* ``teacher_llff`` -- BASELINE config #4's path: a forward-facing rig of fern-like cameras (36 x 48), rays through the NDC warp, near / far 0 / 1,
+                 ``data_type = 'llff'`` (nerf_process.py:224-226), images of a random teacher rendered the same way,
 
 saved and re-loaded through the reference's checkpoint format, and then compared with the pinned CPU oracle ON THE TRAINED WEIGHTS:
 
@@ -34,20 +36,45 @@ from oracle import restate as R
 pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda:0")
 D, WD, SC, NF = 8, 256, 64, 128
-HS = WS = 48
 N_IMG, N_STEPS, N_RAYS = 8, 4000, 1024
-SCENES = ("teacher", "solids")
+SCENES = ("teacher", "solids", "teacher_llff")
 
 
-def _opts(**kw):
-    base = dict(near=2.0, far=6.0, N_samples_c=SC, N_samples_f=NF, perturb=1.0, chunk_rays=4096, chunk_pts=524288, data_type="blender",
+def _geo(scene):
+    """Frame size, full-resolution camera, depth range and data type of a scene."""
+    if scene.endswith("_llff"):
+        Kf, Hf, Wf = synthetic.fern_camera()
+        return SimpleNamespace(llff=True, HS=36, WS=48, Kf=Kf, Hf=Hf, Wf=Wf, near=0.0, far=1.0, data_type="llff")
+    Kf, Hf, Wf = synthetic.lego_camera()
+    return SimpleNamespace(llff=False, HS=48, WS=48, Kf=Kf, Hf=Hf, Wf=Wf, near=2.0, far=6.0, data_type="blender")
+
+
+def _opts(geo, **kw):
+    base = dict(near=geo.near, far=geo.far, N_samples_c=SC, N_samples_f=NF, perturb=1.0, chunk_rays=4096, chunk_pts=524288, data_type=geo.data_type,
                 gpu_ids=[0], rank=0, exp_name="trained", N_rays=N_RAYS, global_batch=True, idx_save=N_STEPS, n_angle=N_IMG + 1,
                 single_angle=-1, phi=-30.0, nf=4.0, precision="fp32")
     base.update(kw)
     return SimpleNamespace(**base)
 
 
-def _solids_images(K, poses):
+def _cfg(geo):
+    return R.PathConfig(near=geo.near, far=geo.far, N_samples_c=SC, N_samples_f=NF, perturb=1.0, netDepth=D, netWidth=WD, data_type=geo.data_type)
+
+
+def _llff_poses():
+    """A forward-facing rig: the fern-like camera (synthetic.fern_pose) moved round a small circle in its image plane; the last one (held out) at the centre."""
+    base = torch.from_numpy(synthetic.fern_pose()).float()
+    poses = []
+    for i in range(N_IMG + 1):
+        p = base.clone()
+        if i < N_IMG:
+            th = 2.0 * np.pi * i / N_IMG
+            p[:3, 3] += torch.tensor([0.15 * np.cos(th), 0.15 * np.sin(th), 0.03 * np.sin(2 * th)], dtype=torch.float32)
+        poses.append(p)
+    return torch.stack(poses, 0)
+
+
+def _solids_images(K, poses, HS=48, WS=48):
     """Ground truth of the analytic scene: 1024 uniform depths per ray, float64, alpha-composited on white (plain torch, test-only)."""
     imgs = []
     for pose in poses:
@@ -79,22 +106,23 @@ def _solids_images(K, poses):
 def trained(request, tmp_path_factory):
     """Train once per scene; everything below reads the weights back from the reference-format checkpoint."""
     scene = request.param
+    geo = _geo(scene)
+    HS, WS = geo.HS, geo.WS
     tmp = str(tmp_path_factory.mktemp(f"ckpt_{scene}"))
     torch.manual_seed(11)
     NP.manual_seed(5)
-    K800, _, _ = synthetic.lego_camera()
-    K = np.array([[K800[0][0] * WS / 800.0, 0, WS / 2], [0, K800[1][1] * HS / 800.0, HS / 2], [0, 0, 1]])
+    K = np.array([[geo.Kf[0][0] * WS / geo.Wf, 0, WS / 2], [0, geo.Kf[1][1] * HS / geo.Hf, HS / 2], [0, 0, 1]])
     posenc = get_positional_encoder(10), get_positional_encoder(4)
-    poses = harness.get_render_pose(n_angle=N_IMG + 1, phi=-30.0, nf=4.0)
-    opts = _opts()
-    if scene == "teacher":
+    poses = _llff_poses() if geo.llff else harness.get_render_pose(n_angle=N_IMG + 1, phi=-30.0, nf=4.0)
+    opts = _opts(geo)
+    if scene.startswith("teacher"):
         teacher = NeRF(D, WD, 63, 27).to(DEV)
         teacher.load_state_dict({k: torch.as_tensor(v) for k, v in synthetic.make_state_dict(77, D, WD).items()})
         with torch.no_grad():
             imgs = torch.stack([harness._render_pose(teacher, posenc, K, poses[i].to(DEV), (HS, WS), opts)[0].reshape(HS, WS, 3)
                                 for i in range(N_IMG + 1)], 0)
     else:
-        imgs = _solids_images(K, poses)
+        imgs = _solids_images(K, poses, HS, WS)
     assert float(imgs.std()) > 0.05
     train_imgs, test_img = imgs[:N_IMG], imgs[N_IMG:]
     student = NeRF(D, WD, 63, 27).to(DEV)
@@ -120,20 +148,24 @@ def trained(request, tmp_path_factory):
     print(f"\n[{scene}] {N_STEPS} steps of {N_RAYS} rays: held-out PSNR {before:.2f} -> {after:.2f} dB (last training batch {train_psnr:.2f} dB); "
           f"max |weight| {w0:.3f} (init) -> {w1:.3f} (trained)")
     assert after > before + 4.0, (before, after)               # it learnt the scene: these are trained weights, not the initialisation
-    return SimpleNamespace(scene=scene, model=model, sd=sd, K=K, poses=poses, posenc=posenc, test_img=test_img, psnr=after)
+    return SimpleNamespace(scene=scene, geo=geo, model=model, sd=sd, K=K, poses=poses, posenc=posenc, test_img=test_img, psnr=after)
 
 
 def test_trained_render_rays_vs_oracle(trained):
-    """(i) 1024 full-resolution lego rays of a training pose, 64 + 128 samples, injected randoms, TRAINED weights."""
+    """(i) 1024 full-resolution rays of a training pose (lego 800 x 800; llff: 378 x 504 through the NDC warp), 64 + 128 samples, injected
+    randoms, TRAINED weights."""
     n = 1024
-    K, H, W = synthetic.lego_camera()
+    geo = trained.geo
+    K, H, W = geo.Kf, geo.Hf, geo.Wf
     pix = torch.from_numpy(synthetic.pixel_batch(H, W, n, 1)).to(DEV)
     o, d = ops.make_o_d_pixels(W, H, K, trained.poses[2][:3, :4].numpy(), pix)
+    if geo.llff:
+        o, d = ops.ndc_rays(H, W, float(K[0][0]), 1.0, o, d)                       # nerf_process.py:224-226 (the warp itself: F2)
     rays = torch.cat([o, d], -1).contiguous()
     g = torch.Generator().manual_seed(21)
     t_rand, u = torch.rand(n, SC, generator=g), torch.rand(n, NF, generator=g)
-    opts = _opts()
-    cfg = R.PathConfig(near=2.0, far=6.0, N_samples_c=SC, N_samples_f=NF, perturb=1.0, netDepth=D, netWidth=WD)
+    opts = _opts(geo)
+    cfg = _cfg(geo)
     with torch.no_grad():
         got = NP.render_rays(rays, trained.model, trained.posenc, opts, t_rand=t_rand, u=u, return_intermediates=True)
     ref = R.render_rays(rays.cpu(), trained.sd, cfg, t_rand, u)
@@ -155,18 +187,22 @@ def test_trained_render_rays_vs_oracle(trained):
 
 
 def _oracle_frame(trained, seed, i_frame):
-    o, d = R.make_o_d(WS, HS, trained.K, trained.poses[N_IMG][:3, :4])
-    rays = torch.cat([o.reshape(-1, 3), d.reshape(-1, 3)], -1)
+    geo = trained.geo
+    o, d = R.make_o_d(geo.WS, geo.HS, trained.K, trained.poses[N_IMG][:3, :4])
+    o, d = o.reshape(-1, 3), d.reshape(-1, 3)
+    if geo.llff:
+        o, d = R.ndc_rays(geo.HS, geo.WS, float(trained.K[0][0]), 1.0, o.expand_as(d), d)
+    rays = torch.cat([o.expand_as(d), d], -1)
     s = (seed * 0x9E3779B1 + i_frame) & 0xFFFFFFFF                                 # nerf_process._next_seed
     t_rand = torch.from_numpy(R.counter_uniform(s, 0, 0, rays.shape[0], SC))
     u = torch.from_numpy(R.counter_uniform(s, 1, 0, rays.shape[0], NF))
-    cfg = R.PathConfig(near=2.0, far=6.0, N_samples_c=SC, N_samples_f=NF, perturb=1.0, netDepth=D, netWidth=WD)
-    return R.render_rays(rays, trained.sd, cfg, t_rand, u), rays
+    return R.render_rays(rays, trained.sd, _cfg(geo), t_rand, u), rays
 
 
 def test_trained_heldout_frame_psnr_vs_oracle(trained):
     """(ii) the held-out pose through harness.test (test.py:38-67) vs the oracle's frame of the same pose, both against ground truth."""
-    opts = _opts()
+    opts = _opts(trained.geo)
+    HS, WS = trained.geo.HS, trained.geo.WS
     ref, _ = _oracle_frame(trained, 9, 0)
     gt = trained.test_img[0].reshape(-1, 3).cpu()
     want = float(R.mse2psnr(R.img2mse(ref["rgb_f"], gt)))
@@ -185,12 +221,14 @@ def test_trained_reduced_precision_frames(trained):
     """(iii) the held-out frame in bf16 and f16s: PSNR against the fp32 frame of the same jitter and the change against ground truth."""
     gt = trained.test_img[0].reshape(-1, 3)
     pose = trained.poses[N_IMG].to(DEV)
+    geo = trained.geo
+    HS, WS = geo.HS, geo.WS
     frames = {}
     with torch.no_grad():
         for mode in ("fp32", "f16s", "bf16"):
             NP.manual_seed(9)
-            frames[mode] = harness._render_pose(harness._frozen(trained.model, _opts(precision=mode)), trained.posenc, trained.K, pose, (HS, WS),
-                                                _opts(precision=mode))[0]
+            frames[mode] = harness._render_pose(harness._frozen(trained.model, _opts(geo, precision=mode)), trained.posenc, trained.K, pose, (HS, WS),
+                                                _opts(geo, precision=mode))[0]
     psnr = lambda a, b: float(-10.0 * torch.log10(torch.mean((a - b) ** 2)))
     base = psnr(frames["fp32"], gt)
     line = [f"fp32 {base:.3f} dB vs ground truth"]
