@@ -37,8 +37,8 @@ const char* mi_nerf_last_error(void);
 /* ------------------------------------------------------------------------------------------------
  * Network description.  One NeRFModule: D trunk layers of width W, skip-concat of the encoded
  * position after trunk layer `skip` (so trunk layer skip+1 takes [gamma(x), h]), density / feature /
- * view-direction / colour heads (model/NeRF.py:10-52).  Supported: fp32 inference 2 <= W <= 256 -- the kernels are instantiated for
- * W = 128 and 256, and mi_nerf_pack_weights / mi_nerf_pack_map lay a network of any other width out for the next of the two, with zero
+ * view-direction / colour heads (model/NeRF.py:10-52).  Supported: fp32 inference 2 <= W <= 512 -- the kernels are instantiated for
+ * W = 128, 256 (32 points per wave) and 384, 512 (16 points per wave), and mi_nerf_pack_weights / mi_nerf_pack_map lay a network of any other width out for the next of them, with zero
  * weights and biases for the hidden units it does not have (exactly 0 through the ReLU: the W-wide network's result at the padded width's
  * cost; linear_d is W // 2 wide, model/NeRF.py:28); the training path W in {128, 256}; the bf16 and split-precision variants W = 256;
  * 2 <= D <= 16, L_x <= 10, L_d <= 4 (the kernels evaluate gamma_10 / gamma_4; gamma_L is a prefix of them in the reference's

@@ -107,7 +107,7 @@ int stage_composite_fine_z(const float*, const float*, const float*, int64_t, in
 
 static int check_net_basic(const mi_nerf_net* net) {
     MN_CHECK_ARG(net != nullptr, "net is NULL");
-    MN_CHECK_ARG(net->W >= 2 && net->W <= MAX_KERNEL_WIDTH, "unsupported width W=%d (the fp32 inference kernels run 2 <= W <= %d, padded to 128 / 256 / 512; "
+    MN_CHECK_ARG(net->W >= 2 && net->W <= MAX_KERNEL_WIDTH, "unsupported width W=%d (the fp32 inference kernels run 2 <= W <= %d, padded to 128 / 256 / 384 / 512; "
                  "training, bf16 and split precision: 128 / 256 and 256)", net->W, MAX_KERNEL_WIDTH);
     MN_CHECK_ARG(net->D >= 2 && net->D <= 16, "unsupported depth D=%d", net->D);
     MN_CHECK_ARG(net->L_x >= 0 && net->L_x <= 10 && net->L_d >= 0 && net->L_d <= 4,

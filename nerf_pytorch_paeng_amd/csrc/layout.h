@@ -39,7 +39,7 @@ __host__ __device__ constexpr int pe_ksteps(int L) { return ((3 * L + 2 + 3) / 4
 constexpr int KERNEL_LX = 10, KERNEL_LD = 4;
 
 // The same for the WIDTH (opts.netWidth, config.py:57).  The fp32 inference kernels are instantiated for W = 128 and W = 256 (mlp_fp32.hip:
-// 32 points per wave on v_mfma_f32_32x32x2_f32) and W = 512 (mlp_fp32_wide.hip: 16 points per wave on v_mfma_f32_16x16x4_f32, the shape whose
+// 32 points per wave on v_mfma_f32_32x32x2_f32) and W = 384 and 512 (mlp_fp32_wide.hip: 16 points per wave on v_mfma_f32_16x16x4_f32, the shape whose
 // accumulators and B operands of a 512-wide layer fit one wave's register file; its stream order is the "W16" one below); a network of any
 // other width 2 <= W <= 512 runs on the next instantiated one: the packer lays the blob out for kernel_width(W) and gives the hidden units the
 // network does not have zero weights and zero biases.  Such a unit is exactly 0 before and after its ReLU and multiplies zero weights in the
@@ -47,7 +47,8 @@ constexpr int KERNEL_LX = 10, KERNEL_LD = 4;
 // W-wide network's, at the padded width's cost.  (W / 2, the width of linear_d, is W // 2 as in model/NeRF.py:28.)  The training kernels,
 // the bf16 and the split-precision variants take their native widths only.
 constexpr int MAX_KERNEL_WIDTH = 512;
-__host__ __device__ constexpr int kernel_width(int W) { return W <= 128 ? 128 : (W <= 256 ? 256 : 512); }
+__host__ __device__ constexpr int kernel_width(int W) { return W <= 128 ? 128 : (W <= 256 ? 256 : (W <= 384 ? 384 : 512)); }
+__host__ __device__ constexpr bool wide_kernel_width(int Wk) { return Wk > 256; }      // 384, 512: mlp_fp32_wide.hip and the W16 stream order
 // k-steps of the W16 stream order (mlp_fp32_wide.hip): a k-step of v_mfma_f32_16x16x4_f32 multiplies FOUR input features, one per lane quarter
 // q = lane >> 4.  Encoded inputs: k-step s < ceil(3L / 2) carries the (sin, cos) pairs of two (level, axis) combinations m = 2s + (q >> 1)
 // (level m / 3, axis m % 3; q & 1: 0 sin, 1 cos); then one k-step (p_x, p_y, p_z, 0); zero-padded to a multiple of 4 k-steps.

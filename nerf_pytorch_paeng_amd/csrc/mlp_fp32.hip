@@ -357,7 +357,7 @@ void mlp_fp32_kernel(const MlpArgs a) {
 // ---------------------------------------------------------------------------------------------
 static int check_net(const mi_nerf_net* net) {
     MN_CHECK_ARG(net != nullptr, "net is NULL");
-    MN_CHECK_ARG(net->W >= 2 && net->W <= MAX_KERNEL_WIDTH, "unsupported width W=%d (the fp32 inference kernels run 2 <= W <= %d, padded to 128 / 256 / 512)", net->W, MAX_KERNEL_WIDTH);
+    MN_CHECK_ARG(net->W >= 2 && net->W <= MAX_KERNEL_WIDTH, "unsupported width W=%d (the fp32 inference kernels run 2 <= W <= %d, padded to 128 / 256 / 384 / 512)", net->W, MAX_KERNEL_WIDTH);
     MN_CHECK_ARG(net->D >= 2 && net->D <= 16, "unsupported depth D=%d", net->D);
     MN_CHECK_ARG(net->L_x >= 0 && net->L_x <= KERNEL_LX && net->L_d >= 0 && net->L_d <= KERNEL_LD,
                  "unsupported encoding L_x=%d L_d=%d (the kernels evaluate up to %d / %d frequencies)", net->L_x, net->L_d, KERNEL_LX, KERNEL_LD);
@@ -456,7 +456,7 @@ int mlp_rays_fp32(const mi_nerf_net* net, const void* packed_dev, const float* r
     MN_CHECK_ARG(n_rays >= 0 && S >= 1, "bad sizes n_rays=%lld S=%d", (long long)n_rays, S);
     if (n_rays == 0) return MI_NERF_OK;
     MN_CHECK_ARG(packed_dev && rays_dev && z_dev && raw_dev, "NULL device pointer");
-    if (kernel_width(net->W) == 512) return mlp_rays_fp32_wide(net, packed_dev, rays_dev, z_dev, n_rays, S, raw_dev, st);
+    if (wide_kernel_width(kernel_width(net->W))) return mlp_rays_fp32_wide(net, packed_dev, rays_dev, z_dev, n_rays, S, raw_dev, st);
     MlpArgs a{};
     fill_common(a, net, packed_dev, false);
     a.rays = rays_dev; a.z = z_dev; a.out = raw_dev; a.S = S; a.tpr = (S + 31) / 32;
@@ -506,7 +506,7 @@ int mlp_embedded_fp32(const mi_nerf_net* net, const void* packed_dev, const floa
     MN_CHECK_ARG(n >= 0, "bad n=%lld", (long long)n);
     if (n == 0) return MI_NERF_OK;
     MN_CHECK_ARG(packed_dev && x_dev && out_dev, "NULL device pointer");
-    if (kernel_width(net->W) == 512) return mlp_embedded_fp32_wide(net, packed_dev, x_dev, n, out_dev, st);
+    if (wide_kernel_width(kernel_width(net->W))) return mlp_embedded_fp32_wide(net, packed_dev, x_dev, n, out_dev, st);
     MlpArgs a{};
     fill_common(a, net, packed_dev, true);
     a.x = x_dev; a.out = out_dev; a.n_pts = n;

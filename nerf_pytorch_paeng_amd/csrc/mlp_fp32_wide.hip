@@ -1,5 +1,5 @@
 // mlp_fp32_wide.hip -- the fused positional-encoding + NeRF MLP forward for networks WIDER than 256 (257 <= netWidth <= 512, config.py:57;
-// padded to 512 by the packer, layout.h kernel_width), fp32 MFMA, inference only.
+// padded to 384 or 512 by the packer, layout.h kernel_width), fp32 MFMA, inference only.
 //
 // Replaces the same reference code as mlp_fp32.hip (nerf_process.py:69-85, :190-194 / :206-209; model/NeRF.py:33-52).
 //
@@ -306,9 +306,8 @@ void mlp_fp32_wide_kernel(const WideArgs a) {
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
-template <int MODE>
+template <int W, int MODE>
 static int launch_wide(const WideArgs& args_in, long long n_wtiles, hipStream_t st) {
-    constexpr int W = 512;
     WideArgs args = args_in;
     const size_t lds = RING_BYTES + (size_t)args.side_floats * 4 + 4 * (W / 2) * 4;
     MN_CHECK_ARG(lds <= 160 * 1024, "LDS budget exceeded: %zu bytes (a %d-deep network of width > 256)", lds, args.D);
@@ -354,7 +353,7 @@ int mlp_rays_fp32_wide(const mi_nerf_net* net, const void* packed_dev, const flo
     fill_wide(a, net, packed_dev, false);
     a.rays = rays_dev; a.z = z_dev; a.out = raw_dev; a.S = S; a.tpr = (S + 15) / 16;
     a.n_wtiles = (long long)n_rays * a.tpr; a.n_rays = n_rays;
-    return launch_wide<0>(a, a.n_wtiles, st);
+    return kernel_width(net->W) == 384 ? launch_wide<384, 0>(a, a.n_wtiles, st) : launch_wide<512, 0>(a, a.n_wtiles, st);
 }
 
 int mlp_embedded_fp32_wide(const mi_nerf_net* net, const void* packed_dev, const float* x_dev, int64_t n, float* out_dev, hipStream_t st) {
@@ -362,7 +361,7 @@ int mlp_embedded_fp32_wide(const mi_nerf_net* net, const void* packed_dev, const
     fill_wide(a, net, packed_dev, true);
     a.x = x_dev; a.out = out_dev; a.n_pts = n;
     a.n_wtiles = (n + 15) / 16;
-    return launch_wide<1>(a, a.n_wtiles, st);
+    return kernel_width(net->W) == 384 ? launch_wide<384, 1>(a, a.n_wtiles, st) : launch_wide<512, 1>(a, a.n_wtiles, st);
 }
 
 }  // namespace minerf

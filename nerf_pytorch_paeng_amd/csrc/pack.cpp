@@ -143,7 +143,7 @@ int pack_fp32(const mi_nerf_net* net, const mi_nerf_params* p, void* blob, size_
 
     std::vector<float> stream;
     stream.reserve(L.stream_bytes_full / 4);
-    const bool w16 = W == 512;          // the 512-wide kernel's stream order (same part sizes: a quad is 256 weights in either order)
+    const bool w16 = wide_kernel_width(W);   // the wide kernels' stream order (same part sizes: a quad is 256 weights in either order)
     if (w16) {
         const int NT16 = W / 16;
         emit_part16(stream, p->linear_x_w[0], Wn, in_x, NT16, enc_ksteps16(KERNEL_LX, net->L_x, 0));

@@ -144,7 +144,7 @@ class EmuWide:
     def __init__(self, blob: np.ndarray):
         self.h = _hdr(blob)
         h = self.h
-        assert np.frombuffer(blob[:64].tobytes(), dtype=np.uint32)[1] == 6 and h["W"] == 512        # the W16 stream order
+        assert np.frombuffer(blob[:64].tobytes(), dtype=np.uint32)[1] == 6 and h["W"] in (384, 512)   # the W16 stream order
         self.stream = np.frombuffer(blob[h["stream_off"]:h["stream_off"] + h["full"]].tobytes(), dtype=np.float32).astype(np.float64)
         self.side = np.frombuffer(blob[h["side_off"]:h["side_off"] + 4 * h["side_floats"]].tobytes(), dtype=np.float32).astype(np.float64)
         self.off = _side_offsets(h["D"], h["W"], 3 + 6 * h["L_d"])
@@ -171,7 +171,8 @@ class EmuWide:
                     for r in range(4):
                         acc[t, r] += Dm[4 * Q4 + r, COL16]
         used = self.pos - start
-        assert used % 16 == 0                                               # parts are whole slots in this order
+        assert used % 8 == 0                                                # the kernel's rotating file of 8 A quads
+        self.pos = start + (used + 15) // 16 * 16                           # parts are slot aligned (W = 384: the 24-quad direction part)
         return acc
 
     @staticmethod

@@ -543,12 +543,12 @@ def test_other_network_shapes(D, W):
 
 
 @pytest.mark.parametrize("D,W,skip", [(8, 64, 4), (4, 64, 4), (8, 192, 4), (6, 100, 2), (8, 200, 4), (3, 31, 0), (8, 129, 4),
-                                      (8, 512, 4), (4, 300, 1), (8, 257, 4), (2, 512, -1), (16, 384, 7)])
+                                      (8, 512, 4), (4, 300, 1), (8, 257, 4), (2, 512, -1), (16, 384, 7), (8, 400, 4), (5, 384, 2)])
 def test_network_widths_without_a_kernel_of_their_own(D, W, skip, lego_rays):
     """--netWidth values the reference accepts (config.py:57; model/NeRF.py:24-30 builds any W) but no kernel is instantiated for: the
-    packer lays such a network out for the next kernel width (64 -> 128, 192 -> 256, 300 -> 512) with zero weights for the hidden units it
+    packer lays such a network out for the next kernel width (64 -> 128, 192 -> 256, 300 -> 384, 400 -> 512) with zero weights for the hidden units it
     does not have (csrc/layout.h kernel_width): the kernels' results are the W-wide network's.  Wider than 256 runs on mlp_fp32_wide.hip
-    (16 points per wave on v_mfma_f32_16x16x4_f32; --netWidth 512 itself is a native width of that kernel).  F6-style against the oracle: embedded rows, the fused
+    (16 points per wave on v_mfma_f32_16x16x4_f32; --netWidth 384 and 512 are native widths of that kernel).  F6-style against the oracle: embedded rows, the fused
     rays entry, the whole render_rays step, a module model through batchify; bf16 and split precision refuse such widths."""
     from nerf_pytorch_paeng_amd._lib import MiNerfError
     from nerf_pytorch_paeng_amd.model import NeRF

@@ -84,7 +84,7 @@ def test_blob_emulation_matches_oracle_embedded(D, W, skip):
     np.testing.assert_allclose(out, ref, atol=1e-9, rtol=1e-9)
 
 
-@pytest.mark.parametrize("D,W,skip", [(3, 512, 0), (2, 300, -1), (4, 257, 1)])
+@pytest.mark.parametrize("D,W,skip", [(3, 512, 0), (2, 300, -1), (4, 257, 1), (3, 384, 1), (2, 400, 0)])
 def test_wide_blob_emulation_matches_oracle(D, W, skip):
     """Networks wider than 256 (--netWidth 512, config.py:57): packed for the 512-wide kernel in the W16 stream order (mlp_fp32_wide.hip:
     16 points per wave on v_mfma_f32_16x16x4_f32); tests/blob_emulator.py EmuWide walks the stream as that kernel does.  Embedded mode (the
@@ -94,7 +94,7 @@ def test_wide_blob_emulation_matches_oracle(D, W, skip):
     sd = synthetic.make_state_dict(19, D, W, skips=skips)
     net = weights.infer_net(sd)
     blob = ops.pack_module(sd, "model_fine.", net).numpy()
-    assert blob.nbytes == _lib.lib().mi_nerf_packed_bytes(ctypes.byref(ops.make_net(D, 512, skip)))
+    assert blob.nbytes == _lib.lib().mi_nerf_packed_bytes(ctypes.byref(ops.make_net(D, 384 if W <= 384 else 512, skip)))
     emu = EmuWide(blob)
     rs = np.random.RandomState(2)
     x = rs.uniform(-1, 1, size=(16, 90))

@@ -8,7 +8,7 @@ from nerf_pytorch_paeng_amd import ops, synthetic, weights
 dev = torch.device("cuda:0")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 S = 192
-for W in (256, 512, 384):
+for W in (256, 512, 384, 320):
     sd = synthetic.make_state_dict(0, 8, W)
     packed = weights.PackedNeRF.from_state_dict(sd, dev)
     K, H, Wd = synthetic.lego_camera()
