@@ -1,7 +1,7 @@
 #!/bin/bash
 # Host-side AddressSanitizer + UBSan run of the library's packers, argument checks and layout code (CPU only: GPU ASan is not available on
 # this pool).  Builds build_scratch/libmi_nerf_asan.so with the HOST code instrumented (-fno-gpu-sanitize keeps the device code as shipped)
-# and runs the CPU tests that go through the C ABI against it.  Round 4: 43 tests, no finding.
+# and runs the CPU tests that go through the C ABI against it.  Round 4: 43 tests, no finding; round 5 (padded widths, the W16 packer, the RCCL helpers' argument checks): 148 tests, no finding.
 set -e
 cd "$(dirname "$0")/.."
 LIB=$(python - <<'PY'
@@ -11,4 +11,4 @@ PY
 )
 ASAN=$(/opt/rocm/lib/llvm/bin/clang --print-file-name=libclang_rt.asan-x86_64.so)
 MI_NERF_LIB=$LIB LD_PRELOAD=$ASAN ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
-    python -m pytest tests/test_packing_cpu.py tests/test_model_cpu.py tests/test_harness_cpu.py -x -q
+    python -m pytest tests/test_packing_cpu.py tests/test_model_cpu.py tests/test_harness_cpu.py tests/test_abi_errors_cpu.py -x -q
