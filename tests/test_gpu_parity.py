@@ -314,6 +314,29 @@ def test_mlp_rays_walks_agree(packed_big, lego_rays, n, S):
     assert torch.equal(raw_t, raw)
 
 
+@pytest.mark.parametrize("W,n,S", [(512, 2048, 40), (512, 1500, 40), (384, 2048, 17), (512, 1024, 16), (384, 1023, 33)])
+def test_wide_kernel_walks_agree(lego_rays, W, n, S):
+    """The same for mlp_fp32_wide_kernel (netWidth 384 / 512: 16-sample wave tiles): ray-major walk (2048 rays x 3 tiles on 1024 waves), tile-major
+    (1500 rays: dealing whole rays would cost a round more), one tile per ray, partial last tiles -- single rays bit for bit against the big launch,
+    the whole launch against the unfused route (embed + embedded-mode kernel) and, on a sample of rays, the oracle."""
+    sd = synthetic.make_state_dict(60 + W, 3, W, skips=(0,))
+    packed = weights.PackedNeRF.from_state_dict(sd, DEV)
+    rays = lego_rays[:n].contiguous()
+    z = torch.sort(torch.rand(n, S, generator=torch.Generator().manual_seed(n + S)) * 4 + 2, -1)[0].to(DEV)
+    raw = ops.mlp_rays(packed.net, packed.fine, rays, z)
+    assert torch.isfinite(raw).all()
+    for i in (0, 1, n // 3, n // 2 + 1, n - 2, n - 1):
+        one = ops.mlp_rays(packed.net, packed.fine, rays[i:i + 1].contiguous(), z[i:i + 1].contiguous())
+        assert torch.equal(one[0], raw[i]), i
+    raw2 = ops.mlp_embedded(packed.net, packed.fine, ops.embed(rays, z, 10, 4)).reshape(n, S, 4)
+    close(raw2, raw, 2e-4, 1e-4)
+    pick = torch.tensor([0, 7, n // 2, n - 1])
+    ref = R.mlp_forward(sd, "model_fine.", R.embed(rays[pick.to(DEV)].cpu(), z[pick.to(DEV)].cpu(), 10, 4).double(), 3, 63, 27, skips=(0,),
+                        dtype=torch.float64).reshape(len(pick), S, 4)
+    assert err(raw[pick.to(DEV)], ref) <= 2e-4
+    assert ops.mlp_rays(packed.net, packed.fine, rays[:0].contiguous(), z[:0].contiguous()).shape == (0, S, 4)      # an empty batch launches nothing
+
+
 @pytest.mark.parametrize("S", [64, 192])
 def test_composite_F7(golden, S):
     g = golden("F7_post_process")
