@@ -173,7 +173,7 @@ def _render(rays: torch.Tensor, packed: PackedNeRF, opts, t_rand, u, seed: int, 
     else:
         u = None
     blobs = packed.f16s() if f16s else (packed.bf16() if bf16 else (packed.coarse, packed.fine))
-    rgb_c, disp_c, rgb_f, disp_f, ws = ops.render_rays(packed.net, blobs[0], blobs[1] if Nf > 0 else None, cfg, rays, t_rand, u)
+    rgb_c, disp_c, rgb_f, disp_f, ws = ops.render_rays(packed.kernel_net(bf16, f16s), blobs[0], blobs[1] if Nf > 0 else None, cfg, rays, t_rand, u)
     out = {"rgb_c": rgb_c, "disp_c": disp_c}                        # nerf_process.py:215-216
     if Nf > 0:
         out["rgb_f"], out["disp_f"] = rgb_f, disp_f

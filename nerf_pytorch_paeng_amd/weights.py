@@ -65,6 +65,31 @@ def padded_train_net(net: Net) -> Net:
     return ops.make_net(net.D, 128 if net.W < 128 else 256, net.skip, net.L_x, net.L_d)
 
 
+def padded_256_net(net: Net, what: str) -> Net:
+    """The network the bf16 / split-precision kernels run for ``net``: they exist for W = 256; a narrower network runs as a 256-wide one with
+    zero weights for the hidden units it does not have (``pad_index_map``; the fp32 kernels get the same from the C packer)."""
+    if net.W == 256:
+        return net
+    if not 2 <= net.W < 256:
+        raise MiNerfError(f"the {what} variant is built for netWidth <= 256 (got {net.W}); wider networks run in fp32")
+    return ops.make_net(net.D, 256, net.skip, net.L_x, net.L_d)
+
+
+def padded_state_dict(sd, prefix: str, net: Net, wide: Net) -> Dict[str, np.ndarray]:
+    """One module's parameters (``prefix`` + linear_x.0.weight ...) scattered into the shapes of ``wide`` (zeros elsewhere), keys kept."""
+    flat = np.concatenate([np.asarray(sd[prefix + k].detach().cpu() if isinstance(sd[prefix + k], torch.Tensor) else sd[prefix + k],
+                                      dtype=np.float32).reshape(-1) for k in ops.param_names(net)])
+    out_flat = np.zeros(ops.param_count(wide), dtype=np.float32)
+    out_flat[pad_index_map(net, wide).numpy()] = flat
+    out, off = {}, 0
+    for k in ops.param_names(wide):
+        shp = _param_shape(wide, k)
+        cnt = int(np.prod(shp))
+        out[prefix + k] = out_flat[off:off + cnt].reshape(shp)
+        off += cnt
+    return out
+
+
 def pad_index_map(net: Net, wide: Net) -> torch.Tensor:
     """int64 [param_count(net)]: where each entry of ``net``'s flat parameter vector (module.parameters() order) sits in the flat vector of
     ``wide`` = the same network at a larger width.  Rows keep their index; so do columns, except linear_d's view-direction block, which
@@ -117,21 +142,47 @@ class PackedNeRF:
                         if k.startswith("model_")}
         return self
 
+    def kernel_net(self, bf16: bool = False, f16s: bool = False) -> Net:
+        """The network description to hand to the library WITH the blobs of that mode: the network's own for fp32 (the C packer pads it to
+        a kernel width itself), the 256-wide one for the bf16 / split-precision blobs of a narrower network (padded here)."""
+        if bf16 or f16s:
+            return padded_256_net(self.net, "split-precision" if f16s else "bf16")
+        return self.net
+
+    def _wide_flats(self, wide: Net):
+        """The device-resident flat parameter vectors scattered into the layout of ``wide`` (nn.Module source)."""
+        if wide is self.net:
+            return self._flat
+        idx = pad_index_map(self.net, wide).to(self.device)
+        out = []
+        for flat in self._flat:
+            w = torch.zeros(ops.param_count(wide), dtype=torch.float32, device=self.device)
+            w[idx] = flat
+            out.append(w)
+        return tuple(out)
+
+    def _wide_sd(self, wide: Net):
+        if wide is self.net:
+            return self._sd
+        return {**padded_state_dict(self._sd, "model_coarse.", self.net, wide), **padded_state_dict(self._sd, "model_fine.", self.net, wide)}
+
     def bf16(self) -> Tuple[torch.Tensor, torch.Tensor]:
         """bf16-stream blobs for the bf16 MFMA variant, packed lazily: on the device from the flat parameter vectors when this
         PackedNeRF came from an nn.Module (packed_for() makes a new one per call, so a host round trip here would be paid per
-        call), on the host from the kept state dict otherwise (once)."""
+        call), on the host from the kept state dict otherwise (once).  Pass them to the library with ``kernel_net(bf16=True)``."""
         if self._bf16 is None:
+            wide = self.kernel_net(bf16=True)
             if self._flat is not None:
-                key = (tuple(getattr(self.net, f) for f, _ in Net._fields_), str(self.device))
+                key = (tuple(getattr(wide, f) for f, _ in Net._fields_), str(self.device))
                 if key not in _maps_bf16:
-                    _maps_bf16[key] = ops.pack_map_bf16(self.net).to(self.device)
-                self._bf16 = tuple(ops.pack_apply_bf16(self.net, _maps_bf16[key], flat) for flat in self._flat)
+                    _maps_bf16[key] = ops.pack_map_bf16(wide).to(self.device)
+                self._bf16 = tuple(ops.pack_apply_bf16(wide, _maps_bf16[key], flat) for flat in self._wide_flats(wide))
             else:
                 if self._sd is None:
                     raise MiNerfError("bf16 packing needs the state dict (keep_state=True)")
-                self._bf16 = (ops.pack_module(self._sd, "model_coarse.", self.net, bf16=True).to(self.device),
-                              ops.pack_module(self._sd, "model_fine.", self.net, bf16=True).to(self.device))
+                sd = self._wide_sd(wide)
+                self._bf16 = (ops.pack_module(sd, "model_coarse.", wide, bf16=True).to(self.device),
+                              ops.pack_module(sd, "model_fine.", wide, bf16=True).to(self.device))
         return self._bf16
 
     def f16s(self) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -143,19 +194,21 @@ class PackedNeRF:
         per packing, i.e. per no-grad render call on an nn.Module; a frozen PackedNeRF pays it once): EVERY caller of the split-precision
         mode gets the refusal the host packer gives, not a NaN frame."""
         if self._f16s is None:
+            wide = self.kernel_net(f16s=True)
             if self._flat is not None:
-                key = (tuple(getattr(self.net, f) for f, _ in Net._fields_), str(self.device))
+                key = (tuple(getattr(wide, f) for f, _ in Net._fields_), str(self.device))
                 if key not in _maps_f16s:
-                    _maps_f16s[key] = ops.pack_map_f16s(self.net).to(self.device)
+                    _maps_f16s[key] = ops.pack_map_f16s(wide).to(self.device)
                 self.f16s_out_of_range = torch.zeros(1, dtype=torch.int32, device=self.device)
-                blobs = tuple(ops.pack_apply_f16s(self.net, _maps_f16s[key], flat, self.f16s_out_of_range) for flat in self._flat)
+                blobs = tuple(ops.pack_apply_f16s(wide, _maps_f16s[key], flat, self.f16s_out_of_range) for flat in self._wide_flats(wide))
                 self.check_f16s_range()
                 self._f16s = blobs
             else:
                 if self._sd is None:
                     raise MiNerfError("f16-split packing needs the state dict (keep_state=True)")
-                self._f16s = (ops.pack_module(self._sd, "model_coarse.", self.net, f16s=True).to(self.device),
-                              ops.pack_module(self._sd, "model_fine.", self.net, f16s=True).to(self.device))
+                sd = self._wide_sd(wide)
+                self._f16s = (ops.pack_module(sd, "model_coarse.", wide, f16s=True).to(self.device),
+                              ops.pack_module(sd, "model_fine.", wide, f16s=True).to(self.device))
         return self._f16s
 
     def check_f16s_range(self) -> int:

@@ -572,7 +572,7 @@ def test_network_widths_without_a_kernel_of_their_own(D, W, skip, lego_rays):
     packer lays such a network out for the next kernel width (64 -> 128, 192 -> 256, 300 -> 384, 400 -> 512) with zero weights for the hidden units it
     does not have (csrc/layout.h kernel_width): the kernels' results are the W-wide network's.  Wider than 256 runs on mlp_fp32_wide.hip
     (16 points per wave on v_mfma_f32_16x16x4_f32; --netWidth 384 and 512 are native widths of that kernel).  F6-style against the oracle: embedded rows, the fused
-    rays entry, the whole render_rays step, a module model through batchify; bf16 and split precision refuse such widths."""
+    rays entry, the whole render_rays step, a module model through batchify; bf16 and split precision run widths up to 256 (padded to their one kernel width)."""
     from nerf_pytorch_paeng_amd._lib import MiNerfError
     from nerf_pytorch_paeng_amd.model import NeRF
     skips = (skip,) if skip >= 0 else ()
@@ -607,10 +607,20 @@ def test_network_widths_without_a_kernel_of_their_own(D, W, skip, lego_rays):
     pinned = ops.composite(ops.mlp_rays(packed.net, packed.fine, rays, z_f), z_f, rays)[0]
     assert err(pinned, want["rgb_f"]) <= 2e-5
     assert float(((got["rgb_f"].cpu() - want["rgb_f"]).abs().amax(-1) > 1e-4).float().mean()) <= 0.03
-    # what does not pad says so
-    for kw in (dict(bf16=True), dict(f16s=True)):
-        with pytest.raises(MiNerfError):
-            NP.render_rays(rays, packed, None, opts, t_rand=t_rand, u=u, **kw)
+    # the bf16 and split-precision variants (one kernel width, 256): narrower networks padded by weights.PackedNeRF, wider ones refused
+    if W <= 256:
+        for src in (packed, model):                                       # host packer (state dict) and device packer (live module)
+            with torch.no_grad():
+                g16 = NP.render_rays(rays, src, None, opts, t_rand=t_rand, u=u, f16s=True)
+                gb = NP.render_rays(rays, src, None, opts, t_rand=t_rand, u=u, bf16=True)
+            assert err(g16["rgb_c"], want["rgb_c"]) <= 2e-5, err(g16["rgb_c"], want["rgb_c"])              # fp32-grade
+            assert float(((g16["rgb_f"].cpu() - want["rgb_f"]).abs().amax(-1) > 1e-4).float().mean()) <= 0.03
+            mse = float(torch.mean((gb["rgb_c"].cpu() - want["rgb_c"]) ** 2))
+            assert torch.isfinite(gb["rgb_f"]).all() and -10.0 * np.log10(max(mse, 1e-20)) > 50.0, mse       # bf16-grade (observed 70-80 dB coarse)
+    else:
+        for kw in (dict(bf16=True), dict(f16s=True)):
+            with pytest.raises(MiNerfError, match="netWidth <= 256"):
+                NP.render_rays(rays, packed, None, opts, t_rand=t_rand, u=u, **kw)
     if W > 256:                                                  # training: up to 256 (padded, tests/test_gpu_train.py); wider is inference only
         with pytest.raises((MiNerfError, RuntimeError), match="training kernels exist for netWidth <= 256"):
             NP.render_rays(rays, model, None, opts, t_rand=t_rand, u=u)["rgb_c"].sum().backward()
