@@ -219,6 +219,12 @@ int mi_nerf_all_gather_tiles(void* comm, const float* tile_dev, int rows_local, 
     if (int rc = rccl(&r)) return rc;
     hipStream_t s = (hipStream_t)stream;
     const size_t row_floats = (size_t)W * C;
+    {   // the tile either lies IN the frame at its own block (RCCL's in-place form) or does not touch it: anything between is undefined in RCCL
+        const uintptr_t t0 = (uintptr_t)tile_dev, t1 = t0 + (size_t)rows_local * row_floats * sizeof(float);
+        const uintptr_t f0 = (uintptr_t)frame_dev, f1 = f0 + (size_t)H * row_floats * sizeof(float);
+        const uintptr_t own = f0 + (size_t)block_row0(H, tc->world, tc->rank) * row_floats * sizeof(float);
+        MN_CHECK_ARG(t1 <= f0 || t0 >= f1 || t0 == own, "the tile overlaps the frame but is not this rank's block of it (in place means tile == frame + row0 * W * C)");
+    }
     if (H % tc->world == 0) {                      // equal blocks: gather straight into the frame (in place when the tile already lies in it)
         if (int rc = r->AllGather(tile_dev, frame_dev, (size_t)rows_local * row_floats, 7 /* ncclFloat32 */, tc->comm, s))
             return rccl_fail(r, rc, "ncclAllGather");

@@ -44,7 +44,9 @@ def shard_range(n: int, world: int, rank: int) -> Tuple[int, int]:
 class TileComm:
     """An RCCL communicator of libmi_nerf.so for the tile gather (mi_nerf_comm_* / mi_nerf_all_gather_tiles, include/mi_nerf.h).
     ``TileComm(id_bytes, world, rank, device)`` is collective over all ranks; ``TileComm.unique_id()`` makes the id on rank 0.
-    ``close()`` destroys the communicator (collective too: call it on every rank, before the process group goes away)."""
+    ``close()`` destroys the communicator (collective too: call it on every rank, before the process group goes away).
+    One gather at a time per TileComm: the staging buffer of a ragged split belongs to the communicator, and RCCL orders a communicator's
+    collectives by issue, so gathers of one TileComm go to one stream (the stream the frame is rendered on)."""
 
     def __init__(self, id_bytes: bytes, world: int, rank: int, device):
         self.device = torch.device(device)
@@ -91,6 +93,8 @@ class TileComm:
         Cc = int(local.shape[1])
         rows = local.shape[0] // W
         frame = torch.empty(H * W, Cc, dtype=torch.float32, device=local.device) if out is None else out
+        if tuple(frame.shape) != (H * W, Cc) or frame.device != local.device:
+            raise MiNerfError(f"out must be [{H * W}, {Cc}] on {local.device}, got {tuple(frame.shape)} on {frame.device}")
         need = int(lib().mi_nerf_all_gather_staging_bytes(self.world, H, W, Cc))
         if need and (self._staging is None or self._staging.numel() < need):
             self._staging = torch.empty(need, dtype=torch.uint8, device=local.device)
