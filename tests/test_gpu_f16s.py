@@ -206,8 +206,10 @@ def test_f16s_surface(packed_big, lego_rays):
     assert torch.equal(m["rgb_f"], whole["rgb_f"])
     with pytest.raises(MiNerfError):
         NP.render_rays(rays, packed_big, None, opts, seed=5, f16s=True, bf16=True)
-    with pytest.raises(MiNerfError):                                                        # W = 128: not built for this variant
-        weights.PackedNeRF.from_state_dict(synthetic.make_state_dict(1, 4, 128), DEV).f16s()
+    with pytest.raises(MiNerfError, match="netWidth <= 256"):                               # wider than the variant's one kernel width: refused (narrower pads)
+        weights.PackedNeRF.from_state_dict(synthetic.make_state_dict(1, 4, 320), DEV).f16s()
+    narrow = weights.PackedNeRF.from_state_dict(synthetic.make_state_dict(1, 4, 128), DEV)
+    assert narrow.kernel_net(f16s=True).W == 256 and narrow.f16s()[0].numel() == weights.PackedNeRF.from_state_dict(synthetic.make_state_dict(1, 4, 256), DEV).f16s()[0].numel()
     big = synthetic.make_state_dict(0, 8, 256)
     big["model_fine.linear_feat.weight"] = big["model_fine.linear_feat.weight"].copy()
     big["model_fine.linear_feat.weight"][3, 5] = 7.0e4                                      # beyond the f16 range: refused, not clipped
