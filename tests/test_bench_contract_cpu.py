@@ -12,7 +12,8 @@ REQUIRED = {"metric": str, "value": (int, float), "unit": str, "n_gpus": int, "s
 
 @pytest.mark.parametrize("name", ["r02_bench_n1.json", "r02_bench_n1_bf16.json", "r02_bench_n1_fern.json", "r02_bench_n2_gloo_rehearsal.json",
                                   "r03_bench_n1.json", "r03_bench_n1_bf16.json", "r03_bench_n1_fern.json", "r03_bench_n4_gloo_rehearsal.json",
-                                  "r03_bench_rank3_of_8_alone.json", "r03_bench_n1_with_f16_split.json", "r04_bench_n1.json", "r04_bench_n4_gloo_rehearsal.json"])
+                                  "r03_bench_rank3_of_8_alone.json", "r03_bench_n1_with_f16_split.json", "r04_bench_n1.json", "r04_bench_n4_gloo_rehearsal.json",
+                                  "r05_bench_n1.json", "r05_driver_command_bench_line.json"])
 def test_committed_bench_line_has_the_contract_fields(name):
     path = os.path.join(ROOT, "profiles", name)
     with open(path) as f:
@@ -53,6 +54,11 @@ def test_committed_bench_line_has_the_contract_fields(name):
             assert line["frame_checksum"] == line["collective"]["frame_checksum_rank0"]
     if name.startswith("r04") and line["n_gpus"] == 1:
         assert "collective" not in line                   # the N = 1 line is unchanged
+    if name.startswith("r05"):                            # SURVEY 8(d)'s protocol beside the contract's mean: per-step hipEvent median; CPU baseline median of >= 3 reps
+        assert abs(line["ms_per_step_median"] - line["ms_per_step"]) < 0.01 * line["ms_per_step"] and "hipEvents" in line["ms_per_step_median_is"]
+        assert "median of 3 rep" in line["cpu_baseline"]["sample"]
+        assert line["roofline"]["traffic_is_current"] is (name == "r05_bench_n1.json")   # the profiled run preceded the PMC passes that re-tied traffic.json to the build
+        assert line["frame_checksum"] == 3074984520147328127          # the frame of rounds 4 and 5, bit for bit (one GPU; an N-GPU line must carry the same)
     if line["n_gpus"] == 1 and "cpu_baseline" in line:
         cpu = line["cpu_baseline"]
         for key in ("value", "unit", "cores", "kind", "sample"):
