@@ -96,6 +96,9 @@ def pad_index_map(net: Net, wide: Net) -> torch.Tensor:
     follows the (wider) feature block (model/NeRF.py:28,46: cat([feature, gamma(d)])).  Scattering a network's parameters through this map
     into zeros gives a network that computes the same function: the extra units are exactly 0 through their ReLU.  Their gradients are 0
     too (ReLU'(0) = 0 on the way in, activation 0 on the way out), so gathering the wide gradient through the same map IS the gradient."""
+    ck = tuple(getattr(n, f) for n in (net, wide) for f, _ in Net._fields_)
+    if ck in _pad_maps:
+        return _pad_maps[ck]
     idx, off = [], 0
     for key in ops.param_names(net):
         shp, shp_w = _param_shape(net, key), _param_shape(wide, key)
@@ -110,7 +113,11 @@ def pad_index_map(net: Net, wide: Net) -> torch.Tensor:
         for v in shp_w:
             n *= v
         off += n
-    return torch.cat(idx).to(torch.int64)
+    _pad_maps[ck] = torch.cat(idx).to(torch.int64)
+    return _pad_maps[ck]
+
+
+_pad_maps: Dict[tuple, torch.Tensor] = {}          # (net, wide) -> CPU index map (a few MB at most; built once per pair of shapes)
 
 
 class PackedNeRF:
