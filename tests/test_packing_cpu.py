@@ -487,3 +487,25 @@ def test_f16s_blobs_reconstruct_the_weights_through_their_gather_maps(D, skip, b
             assert frac == 1.0, (k, frac)
         elif k == "linear_feat.weight" or (k.startswith("linear_x.") and k.endswith(".weight") and not k.startswith("linear_x.0.")):
             assert frac >= 256.0 / (256.0 + 63.0) - 1e-6, (k, frac)            # the skip layer's gamma(x) block has no gradient path
+
+
+@pytest.mark.parametrize("D,W,Wk,skip", [(4, 64, 128, 1), (8, 200, 256, 4), (3, 31, 128, 0), (5, 100, 256, -1), (2, 128, 256, -1)])
+def test_padding_a_network_into_a_wider_one_keeps_its_function(D, W, Wk, skip):
+    """weights.pad_index_map / padded_state_dict (the training path's and the bf16 / split-precision packers' way to run a width without kernels
+    of its own): the scattered parameters describe a Wk-wide network that computes the SAME function (oracle, fp64: the extra units are exact
+    zeros), the map is injective, and gathering through it inverts the scatter."""
+    skips = () if skip < 0 else (skip,)
+    sd = synthetic.make_state_dict(23, D, W, skips=skips)
+    net = weights.infer_net(sd)
+    wide = ops.make_net(D, Wk, net.skip, net.L_x, net.L_d)
+    idx = weights.pad_index_map(net, wide)
+    assert idx.numel() == ops.param_count(net) and idx.unique().numel() == idx.numel() and int(idx.max()) < ops.param_count(wide)
+    big = weights.padded_state_dict(sd, "model_fine.", net, wide)
+    assert weights.infer_net({k.replace("model_fine.", "model_coarse."): v for k, v in big.items()}).W == Wk
+    flat = np.concatenate([sd["model_fine." + k].reshape(-1) for k in ops.param_names(net)])
+    flat_big = np.concatenate([big["model_fine." + k].reshape(-1) for k in ops.param_names(wide)])
+    assert np.array_equal(flat_big[idx.numpy()], flat) and np.count_nonzero(flat_big) == np.count_nonzero(flat)
+    x = torch.from_numpy(np.random.RandomState(1).uniform(-1, 1, size=(50, 90)))
+    a = R.mlp_forward(sd, "model_fine.", x, D, 63, 27, skips=skips, dtype=torch.float64)
+    b = R.mlp_forward(big, "model_fine.", x, D, 63, 27, skips=skips, dtype=torch.float64)
+    np.testing.assert_allclose(b.numpy(), a.numpy(), rtol=1e-12, atol=1e-13)      # exact zeros added; torch's GEMM blocks the longer sums differently (last fp64 bits)
