@@ -235,3 +235,16 @@ def test_student_learns_a_teacher_scene(Wd, precision):
     after = harness.test(600, [0], posenc, student, test_img, K, poses[n_img:].to(DEV), (Hs, Ws), opts)["psnr"][0]
     print(f"W={Wd} {precision}: held-out PSNR {before:.1f} dB -> {after:.1f} dB")
     assert after > before + 6.0, (before, after)
+
+
+def test_example_script_runs_the_references_main_loop(tmp_path):
+    """examples/train_eval_render.py: train -> checkpoint -> test -> render (main.py:136-158) on a tiny scene, at a width without kernels of its own."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("train_eval_render", os.path.join(root, "examples", "train_eval_render.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    res = mod.main(["--steps", "60", "--size", "16", "--views", "4", "--out", str(tmp_path), "--net-width", "64", "--render-views", "2"])
+    assert len(res["psnr"]) == 2 and all(np.isfinite(res["psnr"]))
+    assert os.path.exists(tmp_path / "test_result" / "_result.txt") and os.path.exists(tmp_path / "render_result" / "1_rgb.png")
+    assert os.path.exists(harness._ckpt_path(str(tmp_path), "demo", 60))
