@@ -13,7 +13,8 @@ REQUIRED = {"metric": str, "value": (int, float), "unit": str, "n_gpus": int, "s
 @pytest.mark.parametrize("name", ["r02_bench_n1.json", "r02_bench_n1_bf16.json", "r02_bench_n1_fern.json", "r02_bench_n2_gloo_rehearsal.json",
                                   "r03_bench_n1.json", "r03_bench_n1_bf16.json", "r03_bench_n1_fern.json", "r03_bench_n4_gloo_rehearsal.json",
                                   "r03_bench_rank3_of_8_alone.json", "r03_bench_n1_with_f16_split.json", "r04_bench_n1.json", "r04_bench_n4_gloo_rehearsal.json",
-                                  "r05_bench_n1.json", "r05_driver_command_bench_line.json"])
+                                  "r05_bench_n1.json", "r05_driver_command_bench_line.json", "r05_bench_n4_gloo_rehearsal.json",
+                                  "r05_bench_one_rank_rccl_collective.json"])
 def test_committed_bench_line_has_the_contract_fields(name):
     path = os.path.join(ROOT, "profiles", name)
     with open(path) as f:
@@ -54,7 +55,14 @@ def test_committed_bench_line_has_the_contract_fields(name):
             assert line["frame_checksum"] == line["collective"]["frame_checksum_rank0"]
     if name.startswith("r04") and line["n_gpus"] == 1:
         assert "collective" not in line                   # the N = 1 line is unchanged
-    if name.startswith("r05"):                            # SURVEY 8(d)'s protocol beside the contract's mean: per-step hipEvent median; CPU baseline median of >= 3 reps
+    if name in ("r05_bench_n4_gloo_rehearsal.json", "r05_bench_one_rank_rccl_collective.json"):
+        c = line["collective"]                            # round 5: which route assembled the timed frames, and the C ABI's route beside it where RCCL is the backend
+        assert c["tile_gather_route"] == "torch" and c["frame_equal_across_ranks"] is True and c["neighbour_tile_recomputed_equal"] is True
+        if c["backend"] == "nccl":
+            assert c["c_abi"]["equal_to_torch_route_on_every_rank"] is True and c["c_abi"]["all_gather_ms"] > 0
+        else:
+            assert c["c_abi"] is None and line["frame_checksum"] == 3074984520147328127        # four ranks == one rank, bit for bit
+    if name in ("r05_bench_n1.json", "r05_driver_command_bench_line.json"):          # SURVEY 8(d)'s protocol beside the contract's mean: per-step hipEvent median; CPU baseline median of >= 3 reps
         assert abs(line["ms_per_step_median"] - line["ms_per_step"]) < 0.01 * line["ms_per_step"] and "hipEvents" in line["ms_per_step_median_is"]
         assert "median of 3 rep" in line["cpu_baseline"]["sample"]
         assert line["roofline"]["traffic_is_current"] is (name == "r05_bench_n1.json")   # the profiled run preceded the PMC passes that re-tied traffic.json to the build
