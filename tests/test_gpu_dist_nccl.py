@@ -177,6 +177,86 @@ def test_c_abi_tile_gather_with_one_rank(tmp_path):
     assert set(res) == {"alone_lego", "alone_fern", "in_place", "side_stream", "bad_rows_refused", "closed_refused", "group_lego", "group_fern"}
 
 
+def _fake_rccl_worker(rank, world, port, cases, out_dir):
+    """One of `world` processes SHARING cuda:0: the C ABI's gather with tests/c_abi/fake_rccl.cpp in librccl's place (MI_NERF_RCCL_LIB, set by the
+    parent), the unique id travelling over a gloo group."""
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    res = {}
+    try:
+        from nerf_pytorch_paeng_amd import dist as mdist
+        comm = mdist.TileComm.from_group(dev)
+        assert (comm.world, comm.rank) == (world, rank)
+        for H, W, C in cases:
+            frame = torch.rand(H * W, C, generator=torch.Generator().manual_seed(H * 131 + W + C)).to(dev)     # the same on every rank
+            r0, nr = mdist.shard_rows(H, world, rank)
+            tile = frame[r0 * W:(r0 + nr) * W].clone()
+            got = comm.all_gather_tiles(tile, H, W)
+            res[f"{H}x{W}x{C}"] = bool(torch.equal(got, frame))
+            if H % world == 0:                                    # in place: the tile already lies in the frame at its own block
+                buf = torch.full((H * W, C), float("nan"), device=dev)
+                buf[r0 * W:(r0 + nr) * W] = tile
+                comm.all_gather_tiles(buf[r0 * W:(r0 + nr) * W], H, W, out=buf)
+                res[f"{H}x{W}x{C}_in_place"] = bool(torch.equal(buf, frame))
+            try:                                                  # a tile of the neighbour's size is refused where the blocks differ
+                other = mdist.shard_rows(H, world, (rank + 1) % world)[1]
+                if other != nr:
+                    comm.all_gather_tiles(frame[:other * W].clone(), H, W)
+                    res[f"{H}x{W}x{C}_wrong_rows_refused"] = False
+            except mdist.MiNerfError:
+                res[f"{H}x{W}x{C}_wrong_rows_refused"] = True
+            dist.barrier()
+        # the route dist.render_frame / bench.py take, on a rendered frame
+        packed, K, pose, opts = _scene(dev, 25, 12)
+        rgb, disp = mdist.render_frame(25, 12, K, pose, packed, opts, seed=3, via="c_abi")
+        np.save(os.path.join(out_dir, f"rgb_{rank}.npy"), rgb.cpu().numpy())
+        comm.close()
+        mdist.close_tile_comms()
+    finally:
+        dist.destroy_process_group()
+    with open(os.path.join(out_dir, f"res_{rank}.json"), "w") as f:
+        json.dump(res, f)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_c_abi_tile_gather_between_ranks_with_a_stand_in_for_rccl(tmp_path, world):
+    """mi_nerf_all_gather_tiles with MORE THAN ONE rank on the one-GPU box: RCCL refuses two ranks on a device, so tests/c_abi/fake_rccl.cpp (an
+    all-gather between processes through host shared memory, same entry points) is loaded in its place via MI_NERF_RCCL_LIB.  What runs for real
+    is everything of the C ABI around the collective: the communicator's rank / world plumbing, equal blocks straight into the frame and in place,
+    ragged splits (378 rows over 2 / 3 / 4 ranks, 4096 rays over 3) padded in the staging buffer, gathered in place there and un-padded by the copy
+    kernel -- every rank's frame must equal the whole, bit for bit -- and dist.render_frame(via="c_abi") against the one-rank frame."""
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    lib = str(tmp_path / "libfake_rccl.so")
+    r = subprocess.run([hipcc, "-shared", "-fPIC", "-O1", "-x", "hip", "--offload-arch=gfx950", os.path.join(ROOT, "tests", "c_abi", "fake_rccl.cpp"), "-o", lib, "-lrt"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    cases = [(378, 504, 4), (800, 800, 4), (4096, 1, 4), (25, 3, 1), (24, 20, 4)]
+    old = os.environ.get("MI_NERF_RCCL_LIB")
+    os.environ["MI_NERF_RCCL_LIB"] = lib                          # inherited by the spawned ranks; this process never resolves RCCL itself
+    try:
+        mp.spawn(_fake_rccl_worker, args=(world, _free_port(), cases, str(tmp_path)), nprocs=world, join=True)
+    finally:
+        if old is None:
+            os.environ.pop("MI_NERF_RCCL_LIB", None)
+        else:
+            os.environ["MI_NERF_RCCL_LIB"] = old
+    from nerf_pytorch_paeng_amd.dist import render_frame
+    dev = torch.device("cuda:0")
+    packed, K, pose, opts = _scene(dev, 25, 12)
+    rgb, _ = render_frame(25, 12, K, pose, packed, opts, seed=3)           # no process group: one rank
+    for rank in range(world):
+        res = json.load(open(tmp_path / f"res_{rank}.json"))
+        assert res and all(res.values()), (rank, res)
+        assert any(k.endswith("_in_place") for k in res) or world == 3 and not any(H % 3 == 0 for H, _, _ in cases)
+        np.testing.assert_array_equal(np.load(tmp_path / f"rgb_{rank}.npy"), rgb.cpu().numpy())
+
+
 @pytest.mark.parametrize("world,H,W,C", [(8, 378, 504, 4), (8, 800, 800, 4), (3, 4096, 1, 4), (4, 25, 3, 1), (6, 800, 800, 3), (5, 7, 1, 1)])
 def test_unpad_tiles_for_any_world_size(world, H, W, C):
     """The ragged half of mi_nerf_all_gather_tiles without RCCL: a staging buffer as the padded in-place all-gather leaves it for `world`
