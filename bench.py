@@ -175,7 +175,7 @@ TILE_GATHER_ROUTE = "c_abi" if os.environ.get("BENCH_TILE_GATHER") == "c_abi" el
 _c_abi_leg_hung = False
 
 
-def c_abi_gather_leg(dist, mdist, torch, dev, local, full_torch, H, W) -> dict:
+def c_abi_gather_leg(dist, mdist, torch, dev, cdev, local, full_torch, H, W) -> dict:
     """The tile all-gather through the C ABI (mi_nerf_comm_* / mi_nerf_all_gather_tiles) next to the torch.distributed route, on every rank.
     The ranks agree (all-reduce MIN of a flag) that RCCL is loadable BEFORE the collective communicator set-up, so that a rank without it cannot
     leave the others waiting inside ncclCommInitRank; the whole leg runs on a watched thread: a hang costs this sub-object, not the line."""
@@ -191,7 +191,7 @@ def c_abi_gather_leg(dist, mdist, torch, dev, local, full_torch, H, W) -> dict:
                 mdist.TileComm.available()                 # loads librccl (first use): no communicator, no bootstrap socket yet
             except Exception as e:                         # noqa: BLE001
                 ok, out["error"] = 0, repr(e)
-            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            flag = torch.tensor([ok], dtype=torch.int32, device=cdev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag.item()) == 0:
                 out.setdefault("error", "RCCL not loadable on another rank")
@@ -208,9 +208,9 @@ def c_abi_gather_leg(dist, mdist, torch, dev, local, full_torch, H, W) -> dict:
                 torch.cuda.synchronize(dev)
                 if i >= 2:
                     times.append(ev[0].elapsed_time(ev[1]))
-            tm = torch.tensor([statistics.median(times)], dtype=torch.float64, device=dev)
+            tm = torch.tensor([statistics.median(times)], dtype=torch.float64, device=cdev)
             dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-            eq = torch.tensor([int(torch.equal(full, full_torch))], dtype=torch.int32, device=dev)
+            eq = torch.tensor([int(torch.equal(full, full_torch))], dtype=torch.int32, device=cdev)
             dist.all_reduce(eq, op=dist.ReduceOp.MIN)
             mdist.close_tile_comms()
             out.update(all_gather_ms=round(float(tm.item()), 4), equal_to_torch_route_on_every_rank=bool(eq.item()), world_size=comm.world,
@@ -285,8 +285,9 @@ def collective_block(dist, mdist, torch, dev, backend, rank, world, H, W, K, pos
     dist.all_reduce(flags, op=dist.ReduceOp.MIN)
     max_rows = (H + world - 1) // world
     c_abi = None
-    if backend == "nccl" and os.environ.get("BENCH_NO_C_ABI_GATHER") != "1":
-        c_abi = c_abi_gather_leg(dist, mdist, torch, dev, local, full, H, W)
+    # (a gloo rehearsal on one GPU can run the leg too, with a stand-in for librccl named by MI_NERF_RCCL_LIB: tests/c_abi/fake_rccl.cpp)
+    if (backend == "nccl" or os.environ.get("MI_NERF_RCCL_LIB")) and os.environ.get("BENCH_NO_C_ABI_GATHER") != "1":
+        c_abi = c_abi_gather_leg(dist, mdist, torch, dev, cdev, local, full, H, W)
     return {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks": ranks,
             "tile_gather_route": TILE_GATHER_ROUTE, "c_abi": c_abi,
             "distinct_devices": len({(r["host"], r["device"] if r["pci_bus_id"] is None else r["pci_bus_id"]) for r in ranks}),
@@ -590,7 +591,8 @@ def worker(args) -> None:
     def frame(fp):
         if solo:                                                        # this rank's row block only; nothing to gather
             return mdist.render_shard(H, W, K, fp, packed, opts, world, rank, seed=0, bf16=args.bf16), None
-        return mdist.render_frame(H, W, K, fp, packed, opts, seed=0, bf16=args.bf16, via=TILE_GATHER_ROUTE if backend == "nccl" else "torch")
+        return mdist.render_frame(H, W, K, fp, packed, opts, seed=0, bf16=args.bf16,
+                                  via=TILE_GATHER_ROUTE if (backend == "nccl" or os.environ.get("MI_NERF_RCCL_LIB")) else "torch")
 
     if args.frames > 0:
         frame(pose)                                                     # warm-up frame

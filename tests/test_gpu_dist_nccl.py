@@ -230,12 +230,7 @@ def test_c_abi_tile_gather_between_ranks_with_a_stand_in_for_rccl(tmp_path, worl
     is everything of the C ABI around the collective: the communicator's rank / world plumbing, equal blocks straight into the frame and in place,
     ragged splits (378 rows over 2 / 3 / 4 ranks, 4096 rays over 3) padded in the staging buffer, gathered in place there and un-padded by the copy
     kernel -- every rank's frame must equal the whole, bit for bit -- and dist.render_frame(via="c_abi") against the one-rank frame."""
-    import shutil
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    lib = str(tmp_path / "libfake_rccl.so")
-    r = subprocess.run([hipcc, "-shared", "-fPIC", "-O1", "-x", "hip", "--offload-arch=gfx950", os.path.join(ROOT, "tests", "c_abi", "fake_rccl.cpp"), "-o", lib, "-lrt"],
-                       capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr
+    lib = _build_fake_rccl(tmp_path)
     cases = [(378, 504, 4), (800, 800, 4), (4096, 1, 4), (25, 3, 1), (24, 20, 4)]
     old = os.environ.get("MI_NERF_RCCL_LIB")
     os.environ["MI_NERF_RCCL_LIB"] = lib                          # inherited by the spawned ranks; this process never resolves RCCL itself
@@ -255,6 +250,42 @@ def test_c_abi_tile_gather_between_ranks_with_a_stand_in_for_rccl(tmp_path, worl
         assert res and all(res.values()), (rank, res)
         assert any(k.endswith("_in_place") for k in res) or world == 3 and not any(H % 3 == 0 for H, _, _ in cases)
         np.testing.assert_array_equal(np.load(tmp_path / f"rgb_{rank}.npy"), rgb.cpu().numpy())
+
+
+def _build_fake_rccl(tmp_path) -> str:
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    lib = str(tmp_path / "libfake_rccl.so")
+    r = subprocess.run([hipcc, "-shared", "-fPIC", "-O1", "-x", "hip", "--offload-arch=gfx950", os.path.join(ROOT, "tests", "c_abi", "fake_rccl.cpp"), "-o", lib, "-lrt"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return lib
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("workload", ["lego", "fern"])
+def test_bench_four_ranks_assemble_their_frames_through_the_c_abi(tmp_path, workload):
+    """`bench.py --gpus 4` with the TIMED frames assembled by mi_nerf_all_gather_tiles (BENCH_TILE_GATHER=c_abi) and the `collective.c_abi` leg, four
+    live ranks sharing the GPU over gloo with the stand-in for librccl: the line's frame checksum equals the torch route's and the one-rank line's;
+    fern's 378 rows split 95 / 95 / 94 / 94 go through the staging buffer and the un-pad kernel inside the timed region."""
+    lib = _build_fake_rccl(tmp_path)
+    env = dict(os.environ, BENCH_BACKEND="gloo", MI_NERF_RCCL_LIB=lib, BENCH_TILE_GATHER="c_abi", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "3", "--warmup", "1", "--frames", "1", "--no-cpu-baseline", "--no-bf16-leg",
+           "--no-f16s-leg", "--workload", workload]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=850)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    c = line["collective"]
+    assert c["world_size"] == 4 and c["tile_gather_route"] == "c_abi" and c["frame_equal_across_ranks"] is True and c["neighbour_tile_recomputed_equal"] is True
+    assert "error" not in c["c_abi"] and c["c_abi"]["equal_to_torch_route_on_every_rank"] is True and c["c_abi"]["world_size"] == 4
+    assert (c["c_abi"]["staging_bytes"] > 0) == (workload == "fern")
+    env1 = dict(env); env1.pop("MI_NERF_RCCL_LIB"); env1.pop("BENCH_TILE_GATHER"); env1.pop("BENCH_BACKEND")
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--frames", "1", "--no-cpu-baseline", "--no-bf16-leg", "--no-f16s-leg",
+                          "--no-small-batch", "--train-steps", "0", "--workload", workload], env=env1, capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    assert json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])["frame_checksum"] == line["frame_checksum"]
 
 
 @pytest.mark.parametrize("world,H,W,C", [(8, 378, 504, 4), (8, 800, 800, 4), (3, 4096, 1, 4), (4, 25, 3, 1), (6, 800, 800, 3), (5, 7, 1, 1)])
