@@ -15,7 +15,7 @@ not differentiable here (the reference's loss never reads them, train.py:60-66).
 from __future__ import annotations
 
 import weakref
-from typing import Dict, List, Optional, Tuple
+from typing import Dict, List, Optional
 
 import torch
 
