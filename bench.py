@@ -170,7 +170,7 @@ def frame_checksum(torch, rgb, disp) -> int:
     return int((b * (torch.arange(b.numel(), device=b.device, dtype=torch.int64) % 1000003 + 1)).sum().item())
 
 
-C_ABI_LEG_TIMEOUT_S = 120.0
+C_ABI_LEG_TIMEOUT_S = float(os.environ.get("BENCH_C_ABI_TIMEOUT_S", "120"))
 TILE_GATHER_ROUTE = "c_abi" if os.environ.get("BENCH_TILE_GATHER") == "c_abi" else "torch"
 _c_abi_leg_hung = False
 

@@ -53,6 +53,9 @@ int ncclCommInitRank(void** comm, int world, Id id, int rank) {
 
 int ncclAllGather(const void* send, void* recv, size_t count, int dtype, void* comm, hipStream_t stream) {
     Comm* c = (Comm*)comm;
+    static int calls = 0;                                                 // FAKE_RCCL_HANG_AFTER=n: the (n+1)-th gather of this process never returns
+    const char* hang = getenv("FAKE_RCCL_HANG_AFTER");                    // (what a wedged collective looks like to the caller: bench.py's watchdog test)
+    if (hang && ++calls > atoi(hang)) for (;;) sleep(1);
     const size_t bytes = count * 4;
     if (dtype != 7 || bytes > SLOT_BYTES) return 4;                      // ncclFloat32 only
     if (hipStreamSynchronize(stream) != hipSuccess) return 1;

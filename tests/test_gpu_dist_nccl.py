@@ -288,6 +288,24 @@ def test_bench_four_ranks_assemble_their_frames_through_the_c_abi(tmp_path, work
     assert json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])["frame_checksum"] == line["frame_checksum"]
 
 
+@pytest.mark.timeout(600)
+def test_bench_line_survives_a_wedged_c_abi_collective(tmp_path):
+    """The optional `collective.c_abi` leg runs on a watched thread: if its collective never returns (here: the stand-in's 4th all-gather sleeps for
+    ever on every rank) the ranks give up after BENCH_C_ABI_TIMEOUT_S, rank 0 still prints the ONE line -- with `c_abi: {"error": ...}` and everything
+    the torch route measured -- and every rank exits 0 without touching the wedged communicator again."""
+    lib = _build_fake_rccl(tmp_path)
+    env = dict(os.environ, BENCH_BACKEND="gloo", MI_NERF_RCCL_LIB=lib, FAKE_RCCL_HANG_AFTER="3", BENCH_C_ABI_TIMEOUT_S="20", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "BENCH_TILE_GATHER"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--frames", "1", "--no-cpu-baseline", "--no-bf16-leg",
+                        "--no-f16s-leg"], env=env, capture_output=True, text=True, timeout=500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    c = json.loads(lines[0])["collective"]
+    assert "did not finish" in c["c_abi"]["error"] and c["frame_equal_across_ranks"] is True and c["all_gather_ms"] > 0 and c["tile_gather_route"] == "torch"
+
+
 @pytest.mark.parametrize("world,H,W,C", [(8, 378, 504, 4), (8, 800, 800, 4), (3, 4096, 1, 4), (4, 25, 3, 1), (6, 800, 800, 3), (5, 7, 1, 1)])
 def test_unpad_tiles_for_any_world_size(world, H, W, C):
     """The ragged half of mi_nerf_all_gather_tiles without RCCL: a staging buffer as the padded in-place all-gather leaves it for `world`
