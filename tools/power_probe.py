@@ -58,3 +58,43 @@ def run(mode, seconds=4.0):
 
 for m in ("idle", "fp32", "f16s", "bf16", "idle"):
     run(m)
+
+
+# the training step (fp32 and split precision): forward + backward + Adam on the same 4096-ray batch, back to back for ~5 s each
+def run_train(f16s, seconds=5.0):
+    from types import SimpleNamespace
+    from nerf_pytorch_paeng_amd import nerf_process as NP
+    from nerf_pytorch_paeng_amd.model import NeRF, get_positional_encoder
+    model = NeRF(8, 256, 63, 27).to(dev)
+    model.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+    posenc = get_positional_encoder(10), get_positional_encoder(4)
+    opts = SimpleNamespace(near=2.0, far=6.0, N_samples_c=64, N_samples_f=128, perturb=1.0, chunk_rays=4096, chunk_pts=524288, data_type="blender", gpu_ids=[0], rank=0)
+    target = torch.rand(n, 3, device=dev)
+    optim = torch.optim.Adam(model.parameters(), lr=5e-4)
+    samples, stop = [], threading.Event()
+
+    def sampler():
+        while not stop.is_set():
+            samples.append(smi())
+            time.sleep(0.4)
+    t = threading.Thread(target=sampler)
+    t.start()
+    t0, steps = time.perf_counter(), 0
+    while time.perf_counter() - t0 < seconds:
+        rgb_c, _, rgb_f, _ = NP.batchify_rays_and_render_by_chunk(o, d, model, posenc, H, W, K, opts, f16s=f16s)
+        optim.zero_grad()
+        (torch.nn.functional.mse_loss(rgb_c, target) + torch.nn.functional.mse_loss(rgb_f, target)).backward()
+        optim.step()
+        steps += 1
+        if steps % 20 == 0:
+            torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    stop.set(); t.join()
+    pw = sorted(p for p, _ in samples if p == p)
+    print(f"train{' f16s' if f16s else ' fp32'}: {steps} steps, {dt * 1e3:.2f} ms per step; package power median {pw[len(pw) // 2] if pw else float('nan'):.0f} W (max {pw[-1] if pw else float('nan'):.0f}); "
+          f"sclk samples {[c for _, c in samples][len(samples) // 2:][:6]}", flush=True)
+
+
+run_train(False)
+run_train(True)
