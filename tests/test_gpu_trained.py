@@ -9,6 +9,7 @@ this module makes the nearest thing itself: the BASELINE network (D = 8, W = 256
 * ``teacher`` -- images of a fixed random 8 x 256 NeRF rendered by the inference kernels (the scene of test_gpu_harness.py), and
 * ``solids``  -- an analytic scene with hard surfaces in front of the white background (a textured sphere, a box, a chequered slab;
                  ground truth ray-marched in float64 by plain torch), which is what drives a NeRF's weights to lego-like magnitudes, and
+* ``plumbing`` -- BASELINE config #1: the 4 x 128 network, coarse only (N_samples_f = 0), on the solids scene, and
 * ``teacher_llff`` -- BASELINE config #4's path: a forward-facing rig of fern-like cameras (36 x 48), rays through the NDC warp, near / far 0 / 1,
                  ``data_type = 'llff'`` (nerf_process.py:224-226), images of a random teacher rendered the same way,
 
@@ -40,20 +41,22 @@ D, WD, SC, NF = 8, 256, 64, 128
 # one-off run on longer-trained weights (profiles/r05_trained_weights_long.txt: 20 000 steps, 24 views of 96 x 96)
 N_IMG, N_STEPS, N_RAYS = int(os.environ.get("TRAINED_VIEWS", 8)), int(os.environ.get("TRAINED_STEPS", 4000)), 1024
 SIZE = int(os.environ.get("TRAINED_SIZE", 48))
-SCENES = tuple(os.environ.get("TRAINED_SCENES", "teacher,solids,teacher_llff").split(","))
+SCENES = tuple(os.environ.get("TRAINED_SCENES", "teacher,solids,teacher_llff,plumbing").split(","))
 
 
 def _geo(scene):
     """Frame size, full-resolution camera, depth range and data type of a scene."""
     if scene.endswith("_llff"):
         Kf, Hf, Wf = synthetic.fern_camera()
-        return SimpleNamespace(llff=True, HS=SIZE * 3 // 4, WS=SIZE, Kf=Kf, Hf=Hf, Wf=Wf, near=0.0, far=1.0, data_type="llff")
+        return SimpleNamespace(llff=True, HS=SIZE * 3 // 4, WS=SIZE, Kf=Kf, Hf=Hf, Wf=Wf, near=0.0, far=1.0, data_type="llff", D=D, WD=WD, NF=NF)
     Kf, Hf, Wf = synthetic.lego_camera()
-    return SimpleNamespace(llff=False, HS=SIZE, WS=SIZE, Kf=Kf, Hf=Hf, Wf=Wf, near=2.0, far=6.0, data_type="blender")
+    if scene == "plumbing":          # BASELINE config #1: 4 x 128, coarse only (N_samples_f = 0; with D = 4 the skip at 4 never fires), the solids scene
+        return SimpleNamespace(llff=False, HS=SIZE, WS=SIZE, Kf=Kf, Hf=Hf, Wf=Wf, near=2.0, far=6.0, data_type="blender", D=4, WD=128, NF=0)
+    return SimpleNamespace(llff=False, HS=SIZE, WS=SIZE, Kf=Kf, Hf=Hf, Wf=Wf, near=2.0, far=6.0, data_type="blender", D=D, WD=WD, NF=NF)
 
 
 def _opts(geo, **kw):
-    base = dict(near=geo.near, far=geo.far, N_samples_c=SC, N_samples_f=NF, perturb=1.0, chunk_rays=4096, chunk_pts=524288, data_type=geo.data_type,
+    base = dict(near=geo.near, far=geo.far, N_samples_c=SC, N_samples_f=geo.NF, perturb=1.0, chunk_rays=4096, chunk_pts=524288, data_type=geo.data_type,
                 gpu_ids=[0], rank=0, exp_name="trained", N_rays=N_RAYS, global_batch=True, idx_save=N_STEPS, n_angle=N_IMG + 1,
                 single_angle=-1, phi=-30.0, nf=4.0, precision="fp32")
     base.update(kw)
@@ -61,7 +64,12 @@ def _opts(geo, **kw):
 
 
 def _cfg(geo):
-    return R.PathConfig(near=geo.near, far=geo.far, N_samples_c=SC, N_samples_f=NF, perturb=1.0, netDepth=D, netWidth=WD, data_type=geo.data_type)
+    return R.PathConfig(near=geo.near, far=geo.far, N_samples_c=SC, N_samples_f=geo.NF, perturb=1.0, netDepth=geo.D, netWidth=geo.WD, data_type=geo.data_type)
+
+
+def _final(geo, out):
+    """The colours the harness keeps: fine when N_samples_f > 0, else coarse (test.py:42-47)."""
+    return out["rgb_f"] if geo.NF > 0 else out["rgb_c"]
 
 
 def _llff_poses():
@@ -124,11 +132,11 @@ def trained(request, tmp_path_factory):
         with torch.no_grad():
             imgs = torch.stack([harness._render_pose(teacher, posenc, K, poses[i].to(DEV), (HS, WS), opts)[0].reshape(HS, WS, 3)
                                 for i in range(N_IMG + 1)], 0)
-    else:
+    else:                                                            # "solids" and "plumbing": the analytic scene
         imgs = _solids_images(K, poses, HS, WS)
     assert float(imgs.std()) > 0.05
     train_imgs, test_img = imgs[:N_IMG], imgs[N_IMG:]
-    student = NeRF(D, WD, 63, 27).to(DEV)
+    student = NeRF(geo.D, geo.WD, 63, 27).to(DEV)
     optim = torch.optim.Adam(student.parameters(), lr=1e-3, betas=(0.9, 0.999))
     crit = torch.nn.MSELoss()
     getter = harness.global_batch(train_imgs, K, poses[:N_IMG], list(range(N_IMG)), (HS, WS), DEV,
@@ -141,9 +149,9 @@ def trained(request, tmp_path_factory):
         if it % max(1, N_STEPS // 8) == 0:                           # the usual NeRF schedule decays the rate exponentially: 1e-3 -> 1e-4 over the run
             for g in optim.param_groups:
                 g["lr"] = 1e-3 * 0.1 ** (it / N_STEPS)
-    train_psnr = float(out["psnr_f"])
+    train_psnr = float(out["psnr_f" if geo.NF > 0 else "psnr_c"])
     # the trained weights travel through the reference's checkpoint format (train.py:105-114 -> test.py:20-21)
-    model = NeRF(D, WD, 63, 27).to(DEV)
+    model = NeRF(geo.D, geo.WD, 63, 27).to(DEV)
     ck = harness.load_checkpoint(harness._ckpt_path(tmp, opts.exp_name, N_STEPS), model)
     sd = {k: v.cpu().numpy() for k, v in ck["model_state_dict"].items()}
     after = harness.test(N_STEPS, [0], posenc, model, test_img, K, poses[N_IMG:].to(DEV), (HS, WS), opts)["psnr"][0]
@@ -166,7 +174,7 @@ def test_trained_render_rays_vs_oracle(trained):
         o, d = ops.ndc_rays(H, W, float(K[0][0]), 1.0, o, d)                       # nerf_process.py:224-226 (the warp itself: F2)
     rays = torch.cat([o, d], -1).contiguous()
     g = torch.Generator().manual_seed(21)
-    t_rand, u = torch.rand(n, SC, generator=g), torch.rand(n, NF, generator=g)
+    t_rand, u = torch.rand(n, SC, generator=g), (torch.rand(n, geo.NF, generator=g) if geo.NF > 0 else None)
     opts = _opts(geo)
     cfg = _cfg(geo)
     with torch.no_grad():
@@ -174,6 +182,13 @@ def test_trained_render_rays_vs_oracle(trained):
     ref = R.render_rays(rays.cpu(), trained.sd, cfg, t_rand, u)
     e_c = float((got["rgb_c"].cpu() - ref["rgb_c"]).abs().max())
     e_raw_c = float((got["_raw_c"].cpu().reshape(n, SC, 4) - ref["_raw_c"]).abs().max())
+    e_dc = float((got["disp_c"].cpu() - ref["disp_c"]).abs().max())
+    if geo.NF == 0:                                              # coarse only: nothing is resampled, so nothing to pin
+        print(f"\n[{trained.scene}] trained weights, {n} rays (coarse only, {geo.D} x {geo.WD}): rgb_c max err {e_c:.2e}, disp_c {e_dc:.2e} (raw_c {e_raw_c:.2e}, "
+              f"max |raw| {float(ref['_raw_c'].abs().max()):.1f}, max sigma {float(ref['_raw_c'][..., 3].max()):.1f}); rays hitting the scene: "
+              f"{float((ref['_acc_c'] > 0.5).float().mean()) * 100:.0f} %")
+        assert "rgb_f" not in got and e_c <= 2e-5 and e_dc <= 2e-5, (e_c, e_dc)
+        return
     packed = weights.PackedNeRF.from_state_dict(trained.sd, DEV)
     z_f = ref["_z_f"].to(DEV)
     rgb_pin, disp_pin = ops.composite(ops.mlp_rays(packed.net, packed.fine, rays, z_f), z_f, rays)[:2]
@@ -198,7 +213,7 @@ def _oracle_frame(trained, seed, i_frame):
     rays = torch.cat([o.expand_as(d), d], -1)
     s = (seed * 0x9E3779B1 + i_frame) & 0xFFFFFFFF                                 # nerf_process._next_seed
     t_rand = torch.from_numpy(R.counter_uniform(s, 0, 0, rays.shape[0], SC))
-    u = torch.from_numpy(R.counter_uniform(s, 1, 0, rays.shape[0], NF))
+    u = torch.from_numpy(R.counter_uniform(s, 1, 0, rays.shape[0], geo.NF)) if geo.NF > 0 else None
     return R.render_rays(rays, trained.sd, _cfg(geo), t_rand, u), rays
 
 
@@ -208,12 +223,12 @@ def test_trained_heldout_frame_psnr_vs_oracle(trained):
     HS, WS = trained.geo.HS, trained.geo.WS
     ref, _ = _oracle_frame(trained, 9, 0)
     gt = trained.test_img[0].reshape(-1, 3).cpu()
-    want = float(R.mse2psnr(R.img2mse(ref["rgb_f"], gt)))
+    want = float(R.mse2psnr(R.img2mse(_final(trained.geo, ref), gt)))
     NP.manual_seed(9)
     res = harness.test(N_STEPS, [0], trained.posenc, trained.model, trained.test_img, trained.K, trained.poses[N_IMG:].to(DEV), (HS, WS), opts,
                        keep_frames=True)
     got = res["psnr"][0]
-    diff8 = np.abs(res["frames"][0][0].astype(np.int32) - R.to8b(ref["rgb_f"].reshape(HS, WS, 3).numpy()).astype(np.int32))
+    diff8 = np.abs(res["frames"][0][0].astype(np.int32) - R.to8b(_final(trained.geo, ref).reshape(HS, WS, 3).numpy()).astype(np.int32))
     print(f"\n[{trained.scene}] held-out frame: PSNR HIP {got:.4f} dB, oracle {want:.4f} dB (delta {got - want:+.4f}); 8-bit frames differ in "
           f"{(diff8 > 0).mean() * 100:.2f} % of bytes, by at most {diff8.max()}")
     assert abs(got - want) < 0.05, (got, want)
@@ -250,13 +265,13 @@ def test_trained_activation_range(trained):
     ref, rays = _oracle_frame(trained, 9, 0)
     sd_dev = {k: torch.as_tensor(v).to(DEV) for k, v in trained.sd.items()}
     top = {}
-    for prefix, z in (("model_coarse.", ref["_z_c"]), ("model_fine.", ref["_z_f"])):
+    for prefix, z in (("model_coarse.", ref["_z_c"]),) + ((("model_fine.", ref["_z_f"]),) if trained.geo.NF > 0 else ()):
         taps = {}
         x = ops.embed(rays.to(DEV), z.to(DEV).contiguous(), 10, 4)
         with torch.no_grad():
-            raw = R.mlp_forward(sd_dev, prefix, x, D, 63, 27, (4,), taps=taps)
+            raw = R.mlp_forward(sd_dev, prefix, x, trained.geo.D, 63, 27, (4,), taps=taps)
         top[prefix] = max(max(float(v.abs().max()) for v in taps.values()), float(raw.abs().max()))
     wmax = max(float(np.abs(v).max()) for v in trained.sd.values())
-    print(f"\n[{trained.scene}] largest |pre-activation| coarse {top['model_coarse.']:.1f}, fine {top['model_fine.']:.1f}; largest |weight| {wmax:.2f}; "
+    print(f"\n[{trained.scene}] largest |pre-activation| coarse {top['model_coarse.']:.1f}, fine {top.get('model_fine.', float('nan')):.1f}; largest |weight| {wmax:.2f}; "
           f"f16 range 65504 -> headroom {65504.0 / max(top.values()):.0f}x")
     assert max(top.values()) < 65504.0 / 8 and wmax < 65504.0
