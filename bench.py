@@ -16,6 +16,9 @@ Timing: W untimed warm-up steps, then EXACTLY K timed steps between barrier + to
 of the W warm-up steps the same step runs for 60 ms (BENCH_PREWARM_S; untimed, like them; `config.prewarm_ms`): the clock governor takes tens of
 milliseconds to come up from idle and five steps of a 512-ray shard are 5 ms (profiles/r04_prewarm_512_ray_shard.txt); the 4096-ray step is unaffected.
 
+`ms_per_step_median` (SURVEY.md 8(d)'s protocol, beside the contract's mean): max(K, 3) FURTHER steps, each bracketed by hipEvents on the launch stream, median, max
+over ranks; `value` does not come from it.
+
 Scaling: the 4096-ray batch is SHARDED over the N GPUs -- 4096/N contiguous rays per rank
 (512 at N = 8), no data-path collective -- so `value` = 4096 * K / max-over-ranks time is STRONG scaled.
 `value_weak` (every rank renders its own 4096-ray batch, N * 4096 * K / time) is measured in a second leg of
@@ -29,6 +32,10 @@ operands on the f16 matrix pipe, fp32-grade results; an extra leg, never `value`
 three MFMA kernels in that mode), `small_batch` (the same step at 256..2048 rays on
 one GPU: what a rank sees under strong scaling) and `cpu_baseline` (the CPU oracle timed on the host cores;
 rank 0, N = 1 only).
+
+N > 1 lines carry `collective` (collective_block): what the process group saw, the tile all-gather timed, the frame's checksum equal on every rank, a neighbour's tile
+re-rendered and compared -- and, on backend "nccl", `collective.c_abi`: the same tile gathered through the C ABI's own RCCL communicator (mi_nerf_all_gather_tiles) on a
+watched thread, timed and compared bit for bit with the torch.distributed route.  BENCH_TILE_GATHER=c_abi makes that route assemble the TIMED frames.
 
 BENCH_SOLO_RANK=1 with RANK / WORLD_SIZE set rehearses ONE rank's share of an N-rank run alone (no process
 group; the frame leg renders this rank's rows only): the GPU pool admits at most 6 processes on a card, so an
