@@ -150,6 +150,8 @@ def gather_tiles(local: torch.Tensor, H: int, W: int, group=None, force_collecti
         return local
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     if via == "c_abi":
+        if not local.is_cuda:
+            raise MiNerfError(f"via='c_abi' gathers through the library's RCCL communicator and needs tiles on a HIP device (got {local.device}); there is no host fallback")
         _, n_rows = shard_rows(H, world, rank)
         if local.shape[0] != n_rows * W:
             raise ValueError(f"rank {rank}: tile has {local.shape[0]} rays, expected {n_rows * W}")

@@ -128,3 +128,22 @@ def test_assemble_tiles_checks_the_split():
     assert torch.equal(assemble_tiles(tiles, H, W), _tile_of_rows(0, H, W))
     with pytest.raises(ValueError):
         assemble_tiles(tiles[:7] + [tiles[7][:-1]], H, W)
+
+
+def test_c_abi_route_refuses_host_tensors_instead_of_falling_back():
+    """gather_tiles(via="c_abi") is the library's RCCL route: HIP tensors only.  On host tensors (a gloo rehearsal without a GPU) it raises -- it
+    does not quietly take the torch route -- and an unknown route name is an error."""
+    from nerf_pytorch_paeng_amd import dist as mdist
+    from nerf_pytorch_paeng_amd._lib import MiNerfError
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(_free_port())
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        tile = torch.rand(8 * 5, 4)
+        assert torch.equal(mdist.gather_tiles(tile, 8, 5, force_collective=True, via="torch"), tile)
+        with pytest.raises(MiNerfError, match="HIP device"):
+            mdist.gather_tiles(tile, 8, 5, force_collective=True, via="c_abi")
+        with pytest.raises(ValueError):
+            mdist.gather_tiles(tile, 8, 5, via="mpi")
+        assert mdist.gather_tiles(tile, 8, 5, via="c_abi") is tile          # a group of one without force_collective: nothing to gather on either route
+    finally:
+        dist.destroy_process_group()
