@@ -14,7 +14,7 @@ REQUIRED = {"metric": str, "value": (int, float), "unit": str, "n_gpus": int, "s
                                   "r03_bench_n1.json", "r03_bench_n1_bf16.json", "r03_bench_n1_fern.json", "r03_bench_n4_gloo_rehearsal.json",
                                   "r03_bench_rank3_of_8_alone.json", "r03_bench_n1_with_f16_split.json", "r04_bench_n1.json", "r04_bench_n4_gloo_rehearsal.json",
                                   "r05_bench_n1.json", "r05_driver_command_bench_line.json", "r05_bench_n4_gloo_rehearsal.json",
-                                  "r05_bench_one_rank_rccl_collective.json"])
+                                  "r05_bench_one_rank_rccl_collective.json", "r05_bench_n1_fern.json", "r05_bench_n1_bf16.json"])
 def test_committed_bench_line_has_the_contract_fields(name):
     path = os.path.join(ROOT, "profiles", name)
     with open(path) as f:
