@@ -34,8 +34,11 @@ one GPU: what a rank sees under strong scaling) and `cpu_baseline` (the CPU orac
 rank 0, N = 1 only).
 
 N > 1 lines carry `collective` (collective_block): what the process group saw, the tile all-gather timed, the frame's checksum equal on every rank, a neighbour's tile
-re-rendered and compared -- and, on backend "nccl", `collective.c_abi`: the same tile gathered through the C ABI's own RCCL communicator (mi_nerf_all_gather_tiles) on a
-watched thread, timed and compared bit for bit with the torch.distributed route.  BENCH_TILE_GATHER=c_abi makes that route assemble the TIMED frames.
+re-rendered and compared -- and, on backend "nccl", `collective.c_abi` (c_abi_route_leg): the same tile gathered through the C ABI's own RCCL communicator
+(mi_nerf_all_gather_tiles), timed and compared bit for bit with the torch.distributed route, and then THE SAME --frames POSES rendered and assembled through that
+route: `frame_ms_c_abi` / `frame_checksum_c_abi` beside `frame_ms` / `frame_checksum`, so ONE `--gpus N` run times both routes.  That leg runs on a watched thread
+and a HIP stream of its own.  Exit status: 75 when one of its collectives never returned (the line is printed first, with `c_abi.error`), 76 when backend "nccl" ran
+but `collective.distinct_devices` != N (RCCL did not see N GPUs); 0 otherwise.
 
 BENCH_SOLO_RANK=1 with RANK / WORLD_SIZE set rehearses ONE rank's share of an N-rank run alone (no process
 group; the frame leg renders this rank's rows only): the GPU pool admits at most 6 processes on a card, so an
@@ -74,6 +77,17 @@ BF16_POINTS_PER_PASS = 256               # mlp_bf16.hip: a workgroup takes 4 wav
 PREWARM_S = float(os.environ.get("BENCH_PREWARM_S", "0.06"))                 # untimed steps in front of the W warm-up steps: clock ramp from idle (timed_steps)
 LAUNCHER_GRACE_S = float(os.environ.get("BENCH_LAUNCHER_GRACE_S", "10"))     # SIGTERM -> SIGKILL for the survivors of a failed run
 KERNEL_SOURCES = ("mlp_fp32.hip", "mlp_core.h", "layout.h", "common.h")
+METRIC_FALLBACK = "rays/sec (4096-ray batch, 64c+128f samples) + 800\u00d7800 frame render ms"
+
+
+def baseline_metric() -> str:
+    """The metric string, byte for byte as BASELINE.json spells it (800 U+00D7 800); the literal only when the file did not travel."""
+    try:
+        with open(os.path.join(ROOT, "BASELINE.json"), encoding="utf-8") as fh:
+            m = json.load(fh)["metric"]
+        return m if isinstance(m, str) and m else METRIC_FALLBACK
+    except (OSError, ValueError, KeyError):
+        return METRIC_FALLBACK
 
 
 def parse():
@@ -177,53 +191,79 @@ def frame_checksum(torch, rgb, disp) -> int:
     return int((b * (torch.arange(b.numel(), device=b.device, dtype=torch.int64) % 1000003 + 1)).sum().item())
 
 
-C_ABI_LEG_TIMEOUT_S = float(os.environ.get("BENCH_C_ABI_TIMEOUT_S", "120"))
-TILE_GATHER_ROUTE = "c_abi" if os.environ.get("BENCH_TILE_GATHER") == "c_abi" else "torch"
+C_ABI_LEG_TIMEOUT_S = float(os.environ.get("BENCH_C_ABI_TIMEOUT_S", "180"))
+EXIT_C_ABI_HUNG = 75                 # a collective of the library's own RCCL communicator never returned on this rank (the line is still printed first)
+EXIT_RCCL_SAW_FEWER_GPUS = 76        # backend "nccl" but the ranks did not sit on N distinct GPUs: the run says nothing about N GPUs
 _c_abi_leg_hung = False
 
 
-def c_abi_gather_leg(dist, mdist, torch, dev, cdev, local, full_torch, H, W) -> dict:
-    """The tile all-gather through the C ABI (mi_nerf_comm_* / mi_nerf_all_gather_tiles) next to the torch.distributed route, on every rank.
-    The ranks agree (all-reduce MIN of a flag) that RCCL is loadable BEFORE the collective communicator set-up, so that a rank without it cannot
-    leave the others waiting inside ncclCommInitRank; the whole leg runs on a watched thread: a hang costs this sub-object, not the line."""
+def exit_status(hung: bool, backend: str, world: int, collective) -> int:
+    """What a worker leaves with once its line is out: EXIT_C_ABI_HUNG when the C-ABI gather leg never came back on this rank, EXIT_RCCL_SAW_FEWER_GPUS
+    when backend "nccl" ran with `world` ranks on fewer than `world` distinct devices (host + PCI bus id), else 0."""
+    if hung:
+        return EXIT_C_ABI_HUNG
+    if collective is not None and backend == "nccl" and collective.get("distinct_devices") != world:
+        return EXIT_RCCL_SAW_FEWER_GPUS
+    return 0
+
+
+def c_abi_route_leg(dist, mdist, torch, dev, cdev, local, full_torch, H, W, n_frames, render_frame_c_abi, frame_pose, checksum_torch) -> dict:
+    """The library's OWN route to the tile all-gather (mi_nerf_comm_* / mi_nerf_all_gather_tiles: csrc/comm.hip) measured next to the torch.distributed
+    route, on every rank, in ONE run: (1) the communicator set-up (TileComm.from_group: the ranks agree that RCCL is loadable before anything collective);
+    (2) the same tile gathered 12 times, hipEvent-timed, and compared bit for bit with the frame the torch route assembled; (3) when that holds on every
+    rank, the same `--frames` poses rendered and assembled through this route between two barriers -> frame_ms_c_abi + frame_checksum_c_abi.
+
+    The leg runs on a thread of its own AND a HIP stream of its own: if one of its collectives never returns, the stuck work sits on that side stream, the
+    main thread stops waiting after C_ABI_LEG_TIMEOUT_S, issues NO further GPU or process-group call, prints the line with `c_abi.error` and leaves with
+    EXIT_C_ABI_HUNG -- non-zero, so the launcher stops the other ranks and CI sees the hang."""
     import statistics
     import threading
     out = {}
+    torch.cuda.synchronize(dev)                            # nothing of the main stream is pending: the side stream depends on no event of it
+    side = torch.cuda.Stream(dev)
 
     def leg():
         try:
             torch.cuda.set_device(dev)
-            ok = 1
-            try:
-                mdist.TileComm.available()                 # loads librccl (first use): no communicator, no bootstrap socket yet
-            except Exception as e:                         # noqa: BLE001
-                ok, out["error"] = 0, repr(e)
-            flag = torch.tensor([ok], dtype=torch.int32, device=cdev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 0:
-                out.setdefault("error", "RCCL not loadable on another rank")
-                return
-            comm = mdist.tile_comm(dev)
-            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-            times = []
-            for i in range(12):
-                torch.cuda.synchronize(dev)
-                dist.barrier()
-                ev[0].record()
-                full = comm.all_gather_tiles(local, H, W)
-                ev[1].record()
-                torch.cuda.synchronize(dev)
-                if i >= 2:
-                    times.append(ev[0].elapsed_time(ev[1]))
-            tm = torch.tensor([statistics.median(times)], dtype=torch.float64, device=cdev)
-            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-            eq = torch.tensor([int(torch.equal(full, full_torch))], dtype=torch.int32, device=cdev)
-            dist.all_reduce(eq, op=dist.ReduceOp.MIN)
-            mdist.close_tile_comms()
-            out.update(all_gather_ms=round(float(tm.item()), 4), equal_to_torch_route_on_every_rank=bool(eq.item()), world_size=comm.world,
-                       staging_bytes=int(mdist.lib().mi_nerf_all_gather_staging_bytes(comm.world, H, W, int(local.shape[1]))),
-                       what="mi_nerf_all_gather_tiles: libmi_nerf.so's own RCCL communicator (unique id broadcast over the process group), "
-                            "enqueued on the stream the tile was rendered on; hipEvents on that stream, median of 10, max over ranks")
+            with torch.cuda.stream(side):
+                comm = mdist.tile_comm(dev)                # collective; raises MiNerfError on EVERY rank when any rank cannot load librccl
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+                times = []
+                for i in range(12):
+                    side.synchronize()
+                    dist.barrier()
+                    ev[0].record()
+                    full = comm.all_gather_tiles(local, H, W)
+                    ev[1].record()
+                    side.synchronize()
+                    if i >= 2:
+                        times.append(ev[0].elapsed_time(ev[1]))
+                tm = torch.tensor([statistics.median(times)], dtype=torch.float64, device=cdev)
+                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+                eq = torch.tensor([int(torch.equal(full, full_torch))], dtype=torch.int32, device=cdev)
+                dist.all_reduce(eq, op=dist.ReduceOp.MIN)
+                out.update(all_gather_ms=round(float(tm.item()), 4), equal_to_torch_route_on_every_rank=bool(eq.item()), world_size=comm.world,
+                           staging_bytes=int(mdist.lib().mi_nerf_all_gather_staging_bytes(comm.world, H, W, int(local.shape[1]))),
+                           stream="a HIP stream of the leg's own (not torch's default stream): renders, gathers and hipEvents of this leg all sit on it",
+                           what="mi_nerf_all_gather_tiles: libmi_nerf.so's own RCCL communicator (unique id broadcast over the process group), "
+                                "enqueued on the stream the tile was rendered on; hipEvents on that stream, median of 10, max over ranks")
+                if bool(eq.item()) and n_frames > 0:       # the timed frames of the line, once more, assembled by this route
+                    render_frame_c_abi(frame_pose(-1))
+                    side.synchronize()
+                    dist.barrier()
+                    t0 = time.perf_counter()
+                    for f in range(n_frames):
+                        rgb, disp = render_frame_c_abi(frame_pose(f))
+                    side.synchronize()
+                    dist.barrier()
+                    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=cdev)
+                    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+                    cs = frame_checksum(torch, rgb, disp)
+                    same = torch.tensor([int(cs == checksum_torch)], dtype=torch.int32, device=cdev)
+                    dist.all_reduce(same, op=dist.ReduceOp.MIN)
+                    out.update(frame_ms=round(1e3 * float(el.item()) / n_frames, 2), frames=n_frames, frame_checksum=cs,
+                               frame_checksum_equals_torch_route_on_every_rank=bool(same.item()))
+                mdist.close_tile_comms()
         except Exception as e:                             # noqa: BLE001
             out["error"] = repr(e)
 
@@ -233,7 +273,9 @@ def c_abi_gather_leg(dist, mdist, torch, dev, cdev, local, full_torch, H, W) -> 
     if t.is_alive():
         global _c_abi_leg_hung
         _c_abi_leg_hung = True
-        return {"error": f"did not finish within {C_ABI_LEG_TIMEOUT_S:.0f} s"}
+        return {**{k: v for k, v in out.items() if k != "error"},
+                "error": f"hung: the leg did not finish within {C_ABI_LEG_TIMEOUT_S:.0f} s (a collective of the library's RCCL communicator never returned); "
+                         f"this rank leaves with exit status {EXIT_C_ABI_HUNG} after printing the line"}
     return out
 
 
@@ -250,11 +292,13 @@ def collective_block(dist, mdist, torch, dev, backend, rank, world, H, W, K, pos
     neighbour_tile_recomputed_equal   every rank re-renders the row block of rank (r + 1) % N on ITS OWN GPU and compares it bit for bit
                                 with that block of the gathered frame: the gather put each tile where it belongs, and the frame does
                                 not depend on which GPU rendered which rows (dist.py's bit-identity claim, checked on the hardware)
-    tile_gather_route           which route assembled the TIMED frames: "torch" (torch.distributed all_gather_into_tensor) or "c_abi"
-                                (BENCH_TILE_GATHER=c_abi: mi_nerf_all_gather_tiles, the library's own RCCL communicator, on the render stream)
-    c_abi                       backend "nccl" only: the same tile gathered by the C ABI's route (include/mi_nerf.h, csrc/comm.hip) -- timed like
-                                all_gather_ms and compared bit for bit with the torch route's frame on every rank; {"error": ...} instead of
-                                a dead run when RCCL cannot be loaded or the leg does not finish within C_ABI_LEG_TIMEOUT_S"""
+    tile_gather_route           "torch": frame_ms / frame_checksum of the line are frames assembled by torch.distributed all_gather_into_tensor
+    c_abi                       (filled in by the caller from c_abi_route_leg; backend "nccl", or a stand-in named by MI_NERF_RCCL_LIB) the same tile gathered
+                                by the C ABI's route (include/mi_nerf.h, csrc/comm.hip), timed like all_gather_ms and compared bit for bit with the torch
+                                route's frame on every rank, then the SAME --frames poses rendered + assembled through it (frame_ms / frame_checksum; the line
+                                repeats them at top level as frame_ms_c_abi / frame_checksum_c_abi); {"error": ...} when RCCL cannot be loaded or the leg hangs
+
+    Returns (block, local_tile, gathered_frame): the last two feed c_abi_route_leg."""
     import statistics
     cdev = dev if backend == "nccl" else torch.device("cpu")
     me = {"rank": rank, "host": "?", "device": f"cuda:{dev.index}", "name": "?", "pci_bus_id": None, "cus": 0}
@@ -291,17 +335,14 @@ def collective_block(dist, mdist, torch, dev, backend, rank, world, H, W, K, pos
     flags = torch.tensor([int(cs.item() == cs0.item()), int(torch.equal(mine, full[r0 * W:(r0 + nr) * W]))], dtype=torch.int32, device=cdev)
     dist.all_reduce(flags, op=dist.ReduceOp.MIN)
     max_rows = (H + world - 1) // world
-    c_abi = None
-    # (a gloo rehearsal on one GPU can run the leg too, with a stand-in for librccl named by MI_NERF_RCCL_LIB: tests/c_abi/fake_rccl.cpp)
-    if (backend == "nccl" or os.environ.get("MI_NERF_RCCL_LIB")) and os.environ.get("BENCH_NO_C_ABI_GATHER") != "1":
-        c_abi = c_abi_gather_leg(dist, mdist, torch, dev, cdev, local, full, H, W)
-    return {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks": ranks,
-            "tile_gather_route": TILE_GATHER_ROUTE, "c_abi": c_abi,
-            "distinct_devices": len({(r["host"], r["device"] if r["pci_bus_id"] is None else r["pci_bus_id"]) for r in ranks}),
-            "all_gather_ms": round(float(tm.item()), 4), "all_gather_bytes_per_rank": max_rows * W * 4 * 4, "all_gather_bytes_assembled": world * max_rows * W * 4 * 4,
-            "all_gather_timing": "hipEvents around dist.gather_tiles on torch's current stream (the collective is ordered on it), median of 10, max over ranks",
-            "frame_checksum_rank0": int(cs0.item()), "frame_equal_across_ranks": bool(flags[0].item()),
-            "neighbour_tile_recomputed_equal": bool(flags[1].item())}
+    block = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks": ranks,
+             "tile_gather_route": "torch", "c_abi": None,
+             "distinct_devices": len({(r["host"], r["device"] if r["pci_bus_id"] is None else r["pci_bus_id"]) for r in ranks}),
+             "all_gather_ms": round(float(tm.item()), 4), "all_gather_bytes_per_rank": max_rows * W * 4 * 4, "all_gather_bytes_assembled": world * max_rows * W * 4 * 4,
+             "all_gather_timing": "hipEvents around dist.gather_tiles on torch's current stream (the collective is ordered on it), median of 10, max over ranks",
+             "frame_checksum_rank0": int(cs0.item()), "frame_equal_across_ranks": bool(flags[0].item()),
+             "neighbour_tile_recomputed_equal": bool(flags[1].item())}
+    return block, local, full
 
 
 def worker(args) -> None:
@@ -595,20 +636,26 @@ def worker(args) -> None:
 
     # ---- 800x800 frame, rows sharded over the ranks, one all-gather of the tiles ----------------------------
     frame_ms = frame_cs = None
-    def frame(fp):
+    c_abi_route = use_dist and (backend == "nccl" or bool(os.environ.get("MI_NERF_RCCL_LIB"))) and os.environ.get("BENCH_NO_C_ABI_GATHER") != "1"
+
+    def frame_pose(f: int):
+        """Pose of timed frame f (f = -1: the warm-up frame)."""
+        if fern:
+            return synthetic.fern_pose()
+        return pose if f < 0 else synthetic.pose_spherical(3.0 * (f + 1), -30.0, 4.0)
+
+    def frame(fp, via="torch"):
         if solo:                                                        # this rank's row block only; nothing to gather
             return mdist.render_shard(H, W, K, fp, packed, opts, world, rank, seed=0, bf16=args.bf16), None
-        return mdist.render_frame(H, W, K, fp, packed, opts, seed=0, bf16=args.bf16,
-                                  via=TILE_GATHER_ROUTE if (backend == "nccl" or os.environ.get("MI_NERF_RCCL_LIB")) else "torch")
+        return mdist.render_frame(H, W, K, fp, packed, opts, seed=0, bf16=args.bf16, via=via, force_collective=use_dist)
 
     if args.frames > 0:
-        frame(pose)                                                     # warm-up frame
+        frame(frame_pose(-1))                                           # warm-up frame
         torch.cuda.synchronize(dev)
         barrier()
         t0 = time.perf_counter()
         for f in range(args.frames):
-            fpose = synthetic.fern_pose() if fern else synthetic.pose_spherical(3.0 * (f + 1), -30.0, 4.0)
-            rgb, disp = frame(fpose)
+            rgb, disp = frame(frame_pose(f))
         torch.cuda.synchronize(dev)
         barrier()
         frame_ms = 1e3 * max_over_ranks(time.perf_counter() - t0) / args.frames
@@ -621,8 +668,7 @@ def worker(args) -> None:
             barrier()
             t0 = time.perf_counter()
             for f in range(args.frames):
-                fpose = synthetic.fern_pose() if fern else synthetic.pose_spherical(3.0 * (f + 1), -30.0, 4.0)
-                rgb_s, _ = mdist.render_frame(H, W, K, fpose, packed, opts, seed=0, f16s=True)
+                rgb_s, _ = mdist.render_frame(H, W, K, frame_pose(f), packed, opts, seed=0, f16s=True)
             torch.cuda.synchronize(dev)
             barrier()
             f16s_leg["frame_ms"] = round(1e3 * max_over_ranks(time.perf_counter() - t0) / args.frames, 2)
@@ -632,11 +678,17 @@ def worker(args) -> None:
     # ---- N > 1: what the collective saw, so that the first multi-GPU run verifies itself from the driver's record ------------------------
     collective = None
     if use_dist and args.frames > 0 and os.environ.get("BENCH_NO_COLLECTIVE_BLOCK") != "1":
-        collective = collective_block(dist, mdist, torch, dev, backend, rank, world, H, W, K, pose, packed, opts, args.bf16, rgb, disp)
+        collective, tile, gathered = collective_block(dist, mdist, torch, dev, backend, rank, world, H, W, K, pose, packed, opts, args.bf16, rgb, disp)
+        if c_abi_route:
+            # both routes in ONE run: the frames just timed through torch.distributed, now through the library's own RCCL communicator
+            collective["c_abi"] = c_abi_route_leg(dist, mdist, torch, dev, coll_dev, tile, gathered, H, W, args.frames,
+                                                  lambda fp: frame(fp, via="c_abi"), frame_pose, frame_cs)
+        del tile, gathered
+    hung = _c_abi_leg_hung            # from here on a hung rank makes no GPU call and no process-group call: it prints (rank 0) and leaves
 
     # ---- training step: forward + backward + Adam on this rank's 4096-ray batch --------------
     train = None
-    if train_steps > 0 and not args.bf16:
+    if train_steps > 0 and not args.bf16 and not hung:
         from nerf_pytorch_paeng_amd.model import NeRF, get_positional_encoder
         model = NeRF(8, 256, 63, 27).to(dev)
         model.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
@@ -726,7 +778,7 @@ def worker(args) -> None:
 
     # ---- global-batch staging: rays for 100 800x800 training images + epoch shuffle, on the device ----
     staging = None
-    if rank == 0 and world == 1 and not args.bf16 and not fern and train_steps > 0:
+    if rank == 0 and world == 1 and not args.bf16 and not fern and train_steps > 0 and not hung:
         from nerf_pytorch_paeng_amd import harness
         n_img = 100
         imgs = torch.rand(n_img, H, W, 3, device=dev)
@@ -754,7 +806,7 @@ def worker(args) -> None:
 
     # ---- CPU baseline: the oracle (a port: the reference cannot leave the build container) -------------------
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not hung:
         from oracle import restate as R
         # the GPU box gives one GPU's job a 16-core share of a many-core host: do not oversubscribe
         n_thr = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
@@ -794,7 +846,7 @@ def worker(args) -> None:
         head_ms = ms_strong if headline_strong else ms_weak
         per_gpu = n_s if headline_strong else N_RAYS
         line = {
-            "metric": "rays/sec (4096-ray batch, 64c+128f samples) + 800x800 frame render ms",
+            "metric": baseline_metric(),
             "value": round(head_value, 1), "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(head_ms, 4), "ms_per_step_median": None if ms_median is None else round(ms_median, 4),
             "ms_per_step_median_is": "median over max(K, 3) further steps, each bracketed by hipEvents on the launch stream, max over ranks (SURVEY 8(d)); "
@@ -818,6 +870,10 @@ def worker(args) -> None:
         }
         if collective is not None:
             line["collective"] = collective
+            ca = collective.get("c_abi") or {}
+            # the same frames through the library's own RCCL communicator (mi_nerf_all_gather_tiles), timed in this run beside frame_ms
+            line["frame_ms_c_abi"] = ca.get("frame_ms")
+            line["frame_checksum_c_abi"] = ca.get("frame_checksum")
         if solo:
             line["solo_rank"] = {"rank": rank, "of": world, "n_gpus_measured": 1, "what": "BENCH_SOLO_RANK=1: this rank's share of the run timed alone (no process group, "
                                  "no gather); `value` assumes every rank takes as long as this one"}
@@ -835,14 +891,20 @@ def worker(args) -> None:
             line["staging"] = staging
         if cpu is not None:
             line["cpu_baseline"] = cpu
-        print(json.dumps(line), flush=True)
-    if _c_abi_leg_hung:                # a collective of the optional C-ABI leg never returned: its stream cannot be drained; the line is out
+        print(json.dumps(line, ensure_ascii=False), flush=True)
+    status = exit_status(hung, backend, world, collective)
+    if status == EXIT_C_ABI_HUNG:      # its side stream cannot be drained and its communicator cannot be destroyed: no teardown, a status CI can see
         sys.stdout.flush()
-        os._exit(0)
+        sys.stderr.write(f"bench.py: rank {rank}: the C-ABI gather leg hung ({collective['c_abi']['error']})\n")
+        sys.stderr.flush()
+        os._exit(status)
     if use_dist:
         barrier()                      # rank 0 may still be printing / staging: tear the group down together
         mdist.close_tile_comms()
         dist.destroy_process_group()
+    if status:                         # RCCL must have seen N GPUs: N ranks on fewer devices measure nothing about N GPUs
+        sys.stderr.write(f"bench.py: backend nccl with {world} rank(s) but {collective['distinct_devices']} distinct device(s) in collective.ranks\n")
+        sys.exit(status)
 
 
 def main():

@@ -8,6 +8,7 @@
 // synchronisation or cross-stream event separates the last composite launch from the gather.
 #include <dlfcn.h>
 #include <mutex>
+#include <set>
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
@@ -55,6 +56,18 @@ static void load_rccl() {
         snprintf(r.why, sizeof(r.why), "the library lacks one of ncclGetUniqueId / ncclCommInitRank / ncclAllGather / ncclCommDestroy / ncclGetErrorString");
         return;
     }
+    // One HIP runtime per process: a librccl that came in through the fall-back dlopen may bind a libamdhip64 other than the one this library's
+    // launches go to (a torch wheel ships its own); streams and device pointers of one runtime mean nothing to the other.  Refuse it.
+    // (MI_NERF_RCCL_LIB names a library the caller vouches for -- the tests' stand-in links no second runtime.)
+    if (!(env && *env)) {
+        Dl_info mine{}, theirs{};
+        void* their_sym = dlsym(h, "hipGetDevice");          // searched in librccl's own dependency order
+        if (their_sym && dladdr(their_sym, &theirs) && dladdr((void*)&hipGetDevice, &mine) && mine.dli_fbase != theirs.dli_fbase) {
+            snprintf(r.why, sizeof(r.why), "librccl binds another HIP runtime (%.80s) than this library (%.80s)",
+                     theirs.dli_fname ? theirs.dli_fname : "?", mine.dli_fname ? mine.dli_fname : "?");
+            return;
+        }
+    }
     r.handle = h;
 }
 static int rccl(const Rccl** out) {
@@ -72,11 +85,12 @@ static int rccl_fail(const Rccl* r, int rc, const char* what) {
 }
 
 struct TileComm {
-    uint32_t magic;
     RcclComm comm;
     int world, rank, device;
 };
-constexpr uint32_t TILE_COMM_MAGIC = 0x6d6e7463u;       // "mntc"
+// live handles: a handle is valid iff it is in this set (no magic word read through a pointer that may have been freed)
+static std::mutex g_comms_mu;
+static std::set<TileComm*> g_comms;
 
 // rows of rank r when H rows are split into `world` contiguous blocks: the first H % world ranks get one extra row (dist.shard_rows)
 __host__ __device__ inline int block_rows(int H, int world, int r) { return H / world + (r < H % world ? 1 : 0); }
@@ -161,7 +175,11 @@ int mi_nerf_comm_init_rank(const void* id_host, int world, int rank, void** comm
     memcpy(&id, id_host, sizeof(id));
     RcclComm c = nullptr;
     if (int rc = r->CommInitRank(&c, world, id, rank)) return rccl_fail(r, rc, "ncclCommInitRank");
-    TileComm* tc = new TileComm{TILE_COMM_MAGIC, c, world, rank, dev};
+    TileComm* tc = new TileComm{c, world, rank, dev};
+    {
+        std::lock_guard<std::mutex> g(g_comms_mu);
+        g_comms.insert(tc);
+    }
     *comm_out = tc;
     return MI_NERF_OK;
 }
@@ -169,7 +187,10 @@ int mi_nerf_comm_init_rank(const void* id_host, int world, int rank, void** comm
 static int check_comm(void* comm, TileComm** out) {
     MN_CHECK_ARG(comm != nullptr, "comm is NULL");
     TileComm* tc = (TileComm*)comm;
-    MN_CHECK_ARG(tc->magic == TILE_COMM_MAGIC, "comm is not a handle of mi_nerf_comm_init_rank (or was destroyed)");
+    {
+        std::lock_guard<std::mutex> g(g_comms_mu);
+        MN_CHECK_ARG(g_comms.count(tc) == 1, "comm is not a handle of mi_nerf_comm_init_rank (or was destroyed)");
+    }
     *out = tc;
     return MI_NERF_OK;
 }
@@ -184,12 +205,15 @@ int mi_nerf_comm_info(void* comm, int* world_out, int* rank_out, int* device_out
 }
 
 int mi_nerf_comm_destroy(void* comm) {
-    TileComm* tc = nullptr;
-    if (int rc = check_comm(comm, &tc)) return rc;
+    MN_CHECK_ARG(comm != nullptr, "comm is NULL");
+    TileComm* tc = (TileComm*)comm;
+    {   // leave the registry first: a second destroy of the same handle (from any thread) is refused, never a double free
+        std::lock_guard<std::mutex> g(g_comms_mu);
+        MN_CHECK_ARG(g_comms.erase(tc) == 1, "comm is not a handle of mi_nerf_comm_init_rank (or was destroyed)");
+    }
     const Rccl* r = nullptr;
-    if (int rc = rccl(&r)) return rc;
+    if (int rc = rccl(&r)) { delete tc; return rc; }
     const int rc = r->CommDestroy(tc->comm);
-    tc->magic = 0;
     delete tc;
     if (rc) return rccl_fail(r, rc, "ncclCommDestroy");
     return MI_NERF_OK;
@@ -234,6 +258,13 @@ int mi_nerf_all_gather_tiles(void* comm, const float* tile_dev, int rows_local, 
     const size_t need = staging_bytes_for(tc->world, H, W, C);
     MN_CHECK_ARG(staging_dev != nullptr && staging_bytes >= need, "staging: %zu bytes given, %zu needed (mi_nerf_all_gather_staging_bytes)", staging_bytes, need);
     MN_CHECK_ARG((uintptr_t)staging_dev % 16 == 0, "staging must be 16-byte aligned");
+    {   // staging is written by the gather and read by the un-pad kernel while tile is read and frame written: it shares no byte with either
+        const uintptr_t s0 = (uintptr_t)staging_dev, s1 = s0 + need;
+        const uintptr_t t0 = (uintptr_t)tile_dev, t1 = t0 + (size_t)rows_local * row_floats * sizeof(float);
+        const uintptr_t f0 = (uintptr_t)frame_dev, f1 = f0 + (size_t)H * row_floats * sizeof(float);
+        MN_CHECK_ARG(t1 <= s0 || t0 >= s1, "the tile overlaps the staging buffer");
+        MN_CHECK_ARG(f1 <= s0 || f0 >= s1, "the frame overlaps the staging buffer");
+    }
     const size_t max_cnt = (size_t)(H / tc->world + 1) * row_floats;
     float* mine = (float*)staging_dev + (size_t)tc->rank * max_cnt;
     MN_HIP(hipMemcpyAsync(mine, tile_dev, (size_t)rows_local * row_floats * sizeof(float), hipMemcpyDeviceToDevice, s));

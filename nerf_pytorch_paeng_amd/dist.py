@@ -74,13 +74,25 @@ class TileComm:
 
     @classmethod
     def from_group(cls, device, group=None) -> "TileComm":
-        """Bootstrap over an initialised ``torch.distributed`` group: rank 0's id travels in one 128-byte broadcast."""
+        """Bootstrap over an initialised ``torch.distributed`` group: rank 0's id travels in one 128-byte broadcast.
+        Collective, and safe against a rank that cannot take part: every rank first reports "librccl resolved (and, on rank 0, the id
+        made)" into an all-reduce(MIN); when any rank reports 0, EVERY rank raises MiNerfError before the broadcast and before
+        ncclCommInitRank, so no rank is left waiting for one that has already given up."""
         device = torch.device(device)
         world, rank = dist.get_world_size(group), dist.get_rank(group)
         carrier = device if dist.get_backend(group) == "nccl" else torch.device("cpu")
-        t = torch.zeros(COMM_ID_BYTES, dtype=torch.uint8, device=carrier)
-        if rank == 0:
-            t.copy_(torch.frombuffer(bytearray(cls.unique_id()), dtype=torch.uint8))
+        ident, why = bytes(COMM_ID_BYTES), None
+        try:
+            cls.available()
+            if rank == 0:
+                ident = cls.unique_id()
+        except MiNerfError as e:
+            why = e
+        ok = torch.tensor([0 if why is not None else 1], dtype=torch.int32, device=carrier)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        if int(ok.item()) == 0:
+            raise MiNerfError(f"TileComm.from_group: RCCL is not usable on every rank of the group (rank {rank}: {why if why is not None else 'ok here'})")
+        t = torch.frombuffer(bytearray(ident), dtype=torch.uint8).to(carrier)
         dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         return cls(bytes(t.cpu().numpy().tobytes()), world, rank, device)
 
@@ -210,12 +222,14 @@ def render_shard(H: int, W: int, K, pose, model, opts, world: int, rank: int, *,
 
 
 def render_frame(H: int, W: int, K, pose, model, opts, *, seed: int = 0, group=None, bf16: bool = False, f16s: bool = False,
-                 render_rows_fn: Optional[Callable[[int, int], torch.Tensor]] = None, via: str = "torch") -> Tuple[torch.Tensor, torch.Tensor]:
+                 render_rows_fn: Optional[Callable[[int, int], torch.Tensor]] = None, via: str = "torch",
+                 force_collective: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
     """Render one H x W frame sharded over the process group; returns (rgb [H,W,3], disp [H,W]) on every rank.
 
     Counterpart of the per-pose body of the reference's test()/render() harness (test.py:38-53,143-152):
     make_o_d -> batchify_rays_and_render_by_chunk -> pick the fine outputs when N_samples_f > 0.
-    ``render_rows_fn(row0, n_rows) -> [n_rows*W, 4]`` overrides the local renderer (used by CPU tests).
+    ``render_rows_fn(row0, n_rows) -> [n_rows*W, 4]`` overrides the local renderer (used by CPU tests); ``via`` / ``force_collective`` as in
+    ``gather_tiles``.
     """
     if dist.is_available() and dist.is_initialized():
         world, rank = dist.get_world_size(group), dist.get_rank(group)
@@ -225,5 +239,5 @@ def render_frame(H: int, W: int, K, pose, model, opts, *, seed: int = 0, group=N
         local = render_shard(H, W, K, pose, model, opts, world, rank, seed=seed, bf16=bf16, f16s=f16s)
     else:
         local = render_rows_fn(*shard_rows(H, world, rank))
-    full = gather_tiles(local, H, W, group, via=via)
+    full = gather_tiles(local, H, W, group, force_collective=force_collective, via=via)
     return full[:, :3].reshape(H, W, 3), full[:, 3].reshape(H, W)

@@ -30,3 +30,17 @@ def load_golden(name):
 @pytest.fixture(scope="session")
 def golden():
     return load_golden
+
+
+@pytest.fixture(scope="session")
+def fake_rccl_lib(tmp_path_factory):
+    """tests/c_abi/fake_rccl.cpp built once per session: a stand-in for librccl (shared-memory exchange between ranks that SHARE one GPU -- RCCL itself
+    refuses two ranks on a device), named to the library by MI_NERF_RCCL_LIB."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    lib = str(tmp_path_factory.mktemp("fake_rccl") / "libfake_rccl.so")
+    r = subprocess.run([hipcc, "-shared", "-fPIC", "-O1", "-x", "hip", "--offload-arch=gfx950", os.path.join(ROOT, "tests", "c_abi", "fake_rccl.cpp"), "-o", lib, "-lrt"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return lib

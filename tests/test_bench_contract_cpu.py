@@ -72,3 +72,27 @@ def test_committed_bench_line_has_the_contract_fields(name):
         for key in ("value", "unit", "cores", "kind", "sample"):
             assert key in cpu, key
         assert cpu["kind"] in ("reference", "port")
+
+
+def test_metric_string_is_baseline_jsons_byte_for_byte():
+    """`metric` is read from BASELINE.json (800 U+00D7 800), not retyped: a strict comparer of the two strings accepts the line."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    with open(os.path.join(ROOT, "BASELINE.json"), encoding="utf-8") as f:
+        want = json.load(f)["metric"]
+    assert bench.baseline_metric() == want and bench.METRIC_FALLBACK == want and "\u00d7" in want
+    assert json.loads(json.dumps({"metric": bench.baseline_metric()}, ensure_ascii=False))["metric"].encode() == want.encode()
+
+
+def test_worker_exit_status():
+    """0 for a clean run; 75 when the C-ABI gather leg hung on the rank; 76 when backend nccl did not see N distinct GPUs (gloo rehearsals on one
+    card are exempt: they claim nothing about N GPUs)."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.exit_status(False, "nccl", 8, {"distinct_devices": 8}) == 0
+    assert bench.exit_status(False, "nccl", 8, {"distinct_devices": 1}) == bench.EXIT_RCCL_SAW_FEWER_GPUS == 76
+    assert bench.exit_status(False, "gloo", 4, {"distinct_devices": 1}) == 0
+    assert bench.exit_status(False, "nccl", 1, None) == 0
+    assert bench.exit_status(True, "nccl", 8, {"distinct_devices": 8}) == bench.EXIT_C_ABI_HUNG == 75

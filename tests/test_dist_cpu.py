@@ -147,3 +147,35 @@ def test_c_abi_route_refuses_host_tensors_instead_of_falling_back():
         assert mdist.gather_tiles(tile, 8, 5, via="c_abi") is tile          # a group of one without force_collective: nothing to gather on either route
     finally:
         dist.destroy_process_group()
+
+
+def _from_group_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    if rank == 1:
+        os.environ["MI_NERF_RCCL_LIB"] = "/nonexistent/librccl_of_rank_1.so"       # this rank alone cannot resolve RCCL
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from nerf_pytorch_paeng_amd._lib import MiNerfError
+        from nerf_pytorch_paeng_amd.dist import TileComm
+        try:
+            TileComm.from_group(torch.device("cuda", 0))
+            verdict = "made a communicator"
+        except MiNerfError as e:
+            verdict = "MiNerfError: " + str(e)
+        with open(os.path.join(out_dir, f"verdict_{rank}.txt"), "w") as fh:
+            fh.write(verdict)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_from_group_raises_on_every_rank_when_one_rank_has_no_rccl(tmp_path):
+    """TileComm.from_group is collective: a rank that cannot load librccl must not leave the others inside the id broadcast / ncclCommInitRank.
+    The ranks agree first (all-reduce MIN of a flag); all of them raise MiNerfError, the one at fault names the loader's reason."""
+    mp.spawn(_from_group_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    v0, v1 = (open(tmp_path / f"verdict_{r}.txt").read() for r in (0, 1))
+    assert v0.startswith("MiNerfError") and "not usable on every rank" in v0
+    assert v1.startswith("MiNerfError") and "librccl_of_rank_1" in v1

@@ -224,13 +224,13 @@ def _fake_rccl_worker(rank, world, port, cases, out_dir):
 
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("world", [2, 3, 4])
-def test_c_abi_tile_gather_between_ranks_with_a_stand_in_for_rccl(tmp_path, world):
+def test_c_abi_tile_gather_between_ranks_with_a_stand_in_for_rccl(tmp_path, world, fake_rccl_lib):
     """mi_nerf_all_gather_tiles with MORE THAN ONE rank on the one-GPU box: RCCL refuses two ranks on a device, so tests/c_abi/fake_rccl.cpp (an
     all-gather between processes through host shared memory, same entry points) is loaded in its place via MI_NERF_RCCL_LIB.  What runs for real
     is everything of the C ABI around the collective: the communicator's rank / world plumbing, equal blocks straight into the frame and in place,
     ragged splits (378 rows over 2 / 3 / 4 ranks, 4096 rays over 3) padded in the staging buffer, gathered in place there and un-padded by the copy
     kernel -- every rank's frame must equal the whole, bit for bit -- and dist.render_frame(via="c_abi") against the one-rank frame."""
-    lib = _build_fake_rccl(tmp_path)
+    lib = fake_rccl_lib
     cases = [(378, 504, 4), (800, 800, 4), (4096, 1, 4), (25, 3, 1), (24, 20, 4)]
     old = os.environ.get("MI_NERF_RCCL_LIB")
     os.environ["MI_NERF_RCCL_LIB"] = lib                          # inherited by the spawned ranks; this process never resolves RCCL itself
@@ -252,58 +252,25 @@ def test_c_abi_tile_gather_between_ranks_with_a_stand_in_for_rccl(tmp_path, worl
         np.testing.assert_array_equal(np.load(tmp_path / f"rgb_{rank}.npy"), rgb.cpu().numpy())
 
 
-def _build_fake_rccl(tmp_path) -> str:
-    import shutil
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    lib = str(tmp_path / "libfake_rccl.so")
-    r = subprocess.run([hipcc, "-shared", "-fPIC", "-O1", "-x", "hip", "--offload-arch=gfx950", os.path.join(ROOT, "tests", "c_abi", "fake_rccl.cpp"), "-o", lib, "-lrt"],
-                       capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr
-    return lib
-
-
-@pytest.mark.timeout(900)
-@pytest.mark.parametrize("workload", ["lego", "fern"])
-def test_bench_four_ranks_assemble_their_frames_through_the_c_abi(tmp_path, workload):
-    """`bench.py --gpus 4` with the TIMED frames assembled by mi_nerf_all_gather_tiles (BENCH_TILE_GATHER=c_abi) and the `collective.c_abi` leg, four
-    live ranks sharing the GPU over gloo with the stand-in for librccl: the line's frame checksum equals the torch route's and the one-rank line's;
-    fern's 378 rows split 95 / 95 / 94 / 94 go through the staging buffer and the un-pad kernel inside the timed region."""
-    lib = _build_fake_rccl(tmp_path)
-    env = dict(os.environ, BENCH_BACKEND="gloo", MI_NERF_RCCL_LIB=lib, BENCH_TILE_GATHER="c_abi", HSA_ENABLE_IPC_MODE_LEGACY="0")
+@pytest.mark.timeout(600)
+def test_bench_line_survives_a_wedged_c_abi_collective(fake_rccl_lib):
+    """The `collective.c_abi` leg runs on a watched thread and a HIP stream of its own: if one of its collectives never returns (here: the stand-in's 4th
+    all-gather sleeps for ever on every rank) the ranks give up after BENCH_C_ABI_TIMEOUT_S, issue no further GPU or process-group call, rank 0 still prints
+    the ONE line -- with `c_abi: {"error": "hung..."}` and everything the torch route measured -- and the job ends with status 75: a hang is not a success."""
+    lib = fake_rccl_lib
+    env = dict(os.environ, BENCH_BACKEND="gloo", MI_NERF_RCCL_LIB=lib, FAKE_RCCL_HANG_AFTER="3", BENCH_C_ABI_TIMEOUT_S="20", HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "3", "--warmup", "1", "--frames", "1", "--no-cpu-baseline", "--no-bf16-leg",
-           "--no-f16s-leg", "--workload", workload]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=850)
-    assert r.returncode == 0, r.stderr[-3000:]
-    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    c = line["collective"]
-    assert c["world_size"] == 4 and c["tile_gather_route"] == "c_abi" and c["frame_equal_across_ranks"] is True and c["neighbour_tile_recomputed_equal"] is True
-    assert "error" not in c["c_abi"] and c["c_abi"]["equal_to_torch_route_on_every_rank"] is True and c["c_abi"]["world_size"] == 4
-    assert (c["c_abi"]["staging_bytes"] > 0) == (workload == "fern")
-    env1 = dict(env); env1.pop("MI_NERF_RCCL_LIB"); env1.pop("BENCH_TILE_GATHER"); env1.pop("BENCH_BACKEND")
-    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--frames", "1", "--no-cpu-baseline", "--no-bf16-leg", "--no-f16s-leg",
-                          "--no-small-batch", "--train-steps", "0", "--workload", workload], env=env1, capture_output=True, text=True, timeout=600)
-    assert one.returncode == 0, one.stderr[-2000:]
-    assert json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])["frame_checksum"] == line["frame_checksum"]
-
-
-@pytest.mark.timeout(600)
-def test_bench_line_survives_a_wedged_c_abi_collective(tmp_path):
-    """The optional `collective.c_abi` leg runs on a watched thread: if its collective never returns (here: the stand-in's 4th all-gather sleeps for
-    ever on every rank) the ranks give up after BENCH_C_ABI_TIMEOUT_S, rank 0 still prints the ONE line -- with `c_abi: {"error": ...}` and everything
-    the torch route measured -- and every rank exits 0 without touching the wedged communicator again."""
-    lib = _build_fake_rccl(tmp_path)
-    env = dict(os.environ, BENCH_BACKEND="gloo", MI_NERF_RCCL_LIB=lib, FAKE_RCCL_HANG_AFTER="3", BENCH_C_ABI_TIMEOUT_S="20", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "BENCH_TILE_GATHER"):
-        env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--frames", "1", "--no-cpu-baseline", "--no-bf16-leg",
-                        "--no-f16s-leg"], env=env, capture_output=True, text=True, timeout=500)
-    assert r.returncode == 0, r.stderr[-3000:]
+                        "--no-f16s-leg", "--scaling", "strong"], env=env, capture_output=True, text=True, timeout=500)
+    assert r.returncode == 75, (r.returncode, r.stderr[-3000:])
+    assert "the C-ABI gather leg hung" in r.stderr
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
-    c = json.loads(lines[0])["collective"]
-    assert "did not finish" in c["c_abi"]["error"] and c["frame_equal_across_ranks"] is True and c["all_gather_ms"] > 0 and c["tile_gather_route"] == "torch"
+    line = json.loads(lines[0])
+    c = line["collective"]
+    assert c["c_abi"]["error"].startswith("hung") and c["frame_equal_across_ranks"] is True and c["all_gather_ms"] > 0 and c["tile_gather_route"] == "torch"
+    assert line["frame_ms"] > 0 and line["frame_ms_c_abi"] is None and line["frame_checksum_c_abi"] is None
 
 
 @pytest.mark.parametrize("world,H,W,C", [(8, 378, 504, 4), (8, 800, 800, 4), (3, 4096, 1, 4), (4, 25, 3, 1), (6, 800, 800, 3), (5, 7, 1, 1)])
@@ -329,60 +296,29 @@ def _lib_staging_bytes(world, H, W, C):
 
 
 @pytest.mark.timeout(900)
-def test_bench_one_rank_through_rccl():
-    """`python bench.py` with BENCH_FORCE_DIST=1: the worker's RCCL set-up, barriers and max-over-ranks all-reduce at world size 1."""
-    env = dict(os.environ, BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--frames", "0", "--train-steps", "0",
-                        "--no-cpu-baseline", "--no-small-batch", "--no-bf16-leg"], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
-    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert line["n_gpus"] == 1 and line["value"] > 1e5
-    assert "collective" not in line                       # --frames 0: nothing to gather
-
-
-@pytest.mark.timeout(900)
-def test_bench_collective_block_through_rccl_with_one_rank():
-    """The `collective` object of an N > 1 line against RCCL itself, in a group of one rank (what a one-GPU box can show): backend "nccl",
-    the device all-gathered, the tile all-gather timed by hipEvents, the frame checksum and the re-rendered block equal."""
+def test_bench_both_gather_routes_through_rccl_with_one_rank():
+    """`python bench.py` with BENCH_FORCE_DIST=1: the worker's RCCL set-up, barriers and max-over-ranks all-reduce at world size 1, and the `collective`
+    object of an N > 1 line against RCCL ITSELF (what a one-GPU box can show): backend "nccl", the device all-gathered, the tile all-gather timed by
+    hipEvents, the frame checksum and the re-rendered block equal -- and the same frames timed through BOTH routes in the one run: torch.distributed
+    (frame_ms) and the library's own communicator on its side stream (frame_ms_c_abi), with equal checksums."""
     env = dict(os.environ, BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("WORLD_SIZE", None); env.pop("RANK", None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--frames", "1", "--train-steps", "0",
                         "--no-cpu-baseline", "--no-small-batch", "--no-bf16-leg", "--no-f16s-leg"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["value"] > 1e5
     c = line["collective"]
     assert c["backend"] == "nccl" and c["world_size"] == 1 and c["distinct_devices"] == 1 and c["ranks"][0]["cus"] == 256
     assert c["frame_equal_across_ranks"] is True and c["neighbour_tile_recomputed_equal"] is True
     assert 0 < c["all_gather_ms"] < 50 and c["all_gather_bytes_assembled"] == 800 * 800 * 16
-    # the same tile through the C ABI's own communicator (mi_nerf_all_gather_tiles), timed beside it and bit-equal
+    # the same tile through the C ABI's own communicator (mi_nerf_all_gather_tiles), timed beside it and bit-equal ...
     assert c["tile_gather_route"] == "torch" and "error" not in c["c_abi"], c["c_abi"]
     assert c["c_abi"]["equal_to_torch_route_on_every_rank"] is True and 0 < c["c_abi"]["all_gather_ms"] < 50 and c["c_abi"]["world_size"] == 1
     # ... and as the route of the timed frames themselves
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--frames", "1", "--train-steps", "0",
-                        "--no-cpu-baseline", "--no-small-batch", "--no-bf16-leg", "--no-f16s-leg"], env=dict(env, BENCH_TILE_GATHER="c_abi"),
-                       capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
-    line2 = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert line2["collective"]["tile_gather_route"] == "c_abi" and line2["frame_checksum"] == line["frame_checksum"]
-
-
-@pytest.mark.timeout(900)
-def test_bench_launches_its_own_workers():
-    env = dict(os.environ)
-    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
-        env.pop(k, None)
-    if torch.cuda.device_count() < 2:
-        env["BENCH_BACKEND"] = "gloo"                   # two ranks on the one GPU: plumbing rehearsal
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--frames", "1",
-                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=850)
-    assert r.returncode == 0, r.stderr[-2000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]                      # rank 0 prints ONE line
-    j = json.loads(lines[0])
-    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["scaling"] == "strong"
-    assert j["config"]["rays_per_gpu"] == 2048 and j["value"] > 0 and j["value_weak"] > 0
-    assert j["frame_ms_800x800"] > 0 and j["roofline"]["frac"] <= 1.0
+    assert c["c_abi"]["frame_checksum_equals_torch_route_on_every_rank"] is True and c["c_abi"]["frames"] == 1
+    assert line["frame_ms_c_abi"] > 0 and line["frame_checksum_c_abi"] == line["frame_checksum"] == c["frame_checksum_rank0"]
+    assert 0.5 < line["frame_ms_c_abi"] / line["frame_ms"] < 2.0
 
 
 @pytest.mark.timeout(900)

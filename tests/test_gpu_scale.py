@@ -151,11 +151,14 @@ def _bench(extra_args, env_extra, timeout=850):
 
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("workload", ["lego", "fern"])
-def test_bench_four_live_ranks(workload):
+def test_bench_four_live_ranks_time_both_gather_routes(workload, fake_rccl_lib):
     """`python bench.py --gpus 4`: its own launcher, 4 workers, strong + weak legs, the sharded frame with its all-gather (ragged for
-    fern: 95, 95, 94, 94 rows).  gloo when the box has fewer than 4 GPUs (the ranks then share the card)."""
-    env = {} if torch.cuda.device_count() >= 4 else {"BENCH_BACKEND": "gloo"}
-    j = _bench(["--gpus", "4", "--steps", "3", "--warmup", "1", "--frames", "1", "--no-cpu-baseline", "--workload", workload], env)
+    fern: 95, 95, 94, 94 rows -- through the staging buffer and the un-pad kernel) -- timed through BOTH routes in the one run:
+    torch.distributed (frame_ms) and mi_nerf_all_gather_tiles on the library's own communicator (frame_ms_c_abi), equal checksums.
+    On a box with fewer than 4 GPUs the ranks share the card: gloo for the process group, tests/c_abi/fake_rccl.cpp in librccl's place."""
+    real = torch.cuda.device_count() >= 4
+    env = {} if real else {"BENCH_BACKEND": "gloo", "MI_NERF_RCCL_LIB": fake_rccl_lib, "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+    j = _bench(["--gpus", "4", "--steps", "3", "--warmup", "1", "--frames", "1", "--no-cpu-baseline", "--no-f16s-leg", "--workload", workload], env)
     assert j["n_gpus"] == 4 and j["steps"] == 3 and j["scaling"] == "strong"
     assert j["config"]["rays_per_gpu"] == 1024 and j["value"] > 0 and j["value_weak"] > 0
     assert j["frame_ms"] > 0 and j["frame_hw"] == ([378, 504] if workload == "fern" else [800, 800])
@@ -163,21 +166,31 @@ def test_bench_four_live_ranks(workload):
     # the line verifies its own collective: four ranks seen, the gathered frame identical on all of them, every rank's re-render of its
     # neighbour's row block (ragged for fern) equal to that block of the gathered frame
     c = j["collective"]
-    assert c["world_size"] == 4 and c["backend"] == ("nccl" if torch.cuda.device_count() >= 4 else "gloo")
+    assert c["world_size"] == 4 and c["backend"] == ("nccl" if real else "gloo")
     assert [r["rank"] for r in c["ranks"]] == [0, 1, 2, 3] and all(r["cus"] == 256 for r in c["ranks"])
-    assert c["distinct_devices"] == (4 if torch.cuda.device_count() >= 4 else 1)
+    assert c["distinct_devices"] == (4 if real else 1)
     assert c["frame_equal_across_ranks"] is True and c["neighbour_tile_recomputed_equal"] is True and c["all_gather_ms"] > 0
+    # the library's own route, same run: the tile gather bit-equal to the torch route's on every rank, then the same frame(s) timed through it
+    ca = c["c_abi"]
+    assert "error" not in ca and ca["equal_to_torch_route_on_every_rank"] is True and ca["world_size"] == 4 and ca["all_gather_ms"] > 0
+    assert (ca["staging_bytes"] > 0) == (workload == "fern")
+    assert ca["frame_checksum_equals_torch_route_on_every_rank"] is True
+    assert j["frame_ms_c_abi"] > 0 and j["frame_checksum_c_abi"] == j["frame_checksum"]
     # ... and the frame it assembled from four tiles is, bit for bit, the frame ONE rank renders: `frame_checksum` (the fp32 bit patterns
     # of the last timed frame) of this line against a one-GPU run of the same command -- what BENCH (N = 1) and SCALE (N = 8) let a
     # reader check from the driver's records alone
     assert j["frame_checksum"] == c["frame_checksum_rank0"] and isinstance(j["frame_checksum"], int)
     one = _bench(["--gpus", "1", "--steps", "3", "--warmup", "1", "--frames", "1", "--no-cpu-baseline", "--train-steps", "0", "--no-small-batch",
                   "--no-bf16-leg", "--no-f16s-leg", "--workload", workload], {})
-    assert "collective" not in one and one["frame_checksum"] == j["frame_checksum"], (one["frame_checksum"], j["frame_checksum"])
+    assert "collective" not in one and "frame_ms_c_abi" not in one and one["frame_checksum"] == j["frame_checksum"], (one["frame_checksum"], j["frame_checksum"])
+    if workload == "lego":
+        assert one["frame_checksum"] == 3074984520147328127           # the N = 1 line's frame, unchanged since round 4
+        with open(os.path.join(ROOT, "BASELINE.json"), encoding="utf-8") as fh:
+            assert one["metric"] == j["metric"] == json.load(fh)["metric"]
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("workload,rank", [("lego", 0), ("fern", 2), ("lego", 7)])
+@pytest.mark.parametrize("workload,rank", [("fern", 2), ("lego", 7)])
 def test_bench_one_rank_of_eight_alone(workload, rank):
     """Rank r of the driver's 8-GPU run, alone on this GPU: the 512-ray shard (both legs), its 100 (lego) or 47-48 (fern) frame rows."""
     j = _bench(["--gpus", "8", "--steps", "3", "--warmup", "1", "--frames", "1", "--no-cpu-baseline", "--workload", workload],
