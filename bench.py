@@ -791,17 +791,38 @@ def worker(args) -> None:
         e0.record()
         rr = ops.rays_rgb(W, H, K, p34, imgs)
         e1.record()
-        rr2 = ops.permute_rows(rr, perm)
+        rr2 = ops.permute_rows(rr, perm)                          # the reference's form (np.random.shuffle of the table): for the record only
         e2.record()
         torch.cuda.synchronize(dev)
+        # what the training loop does since round 6: the table stays unshuffled, a step gathers its B rows through the permutation
+        import statistics
+        shuffled = harness.ShuffledRows(rr, perm)
+        gev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(50)]
+        for i, (g0, g1) in enumerate(gev):
+            g0.record()
+            batch = shuffled[i * N_RAYS:(i + 1) * N_RAYS]
+            g1.record()
+        torch.cuda.synchronize(dev)
+        assert torch.equal(batch, rr2[49 * N_RAYS:50 * N_RAYS])
+        gather_us = 1e3 * statistics.median(g0.elapsed_time(g1) for g0, g1 in gev[5:])
         n_rays_gb = n_img * H * W
         b_gen = n_rays_gb * (12 + 36)                     # read the pixel, write (o, d, rgb)
         b_perm = n_rays_gb * (36 + 36 + 8)                # gather + write + the permutation itself
-        staging = {"what": f"main.py:92-102 on the device: rays_rgb for {n_img} {H}x{W} images ({n_rays_gb * 36 / 1e9:.2f} GB) + row shuffle",
+        # a random 36-byte row is one 128-byte HBM request, two when it straddles a line (offsets 96..124 of 128: 8 of 32 four-byte positions)
+        b_perm_hbm = n_rays_gb * (128 * 1.25 + 36 + 8)
+        staging = {"what": f"main.py:92-102 on the device: rays_rgb for {n_img} {H}x{W} images ({n_rays_gb * 36 / 1e9:.2f} GB); the epoch shuffle is a permutation "
+                           f"held beside the table (harness.ShuffledRows), a step gathers its {N_RAYS} rows through it (train.py:29)",
                    "rays_rgb_ms": round(e0.elapsed_time(e1), 3), "rays_rgb_GBps": round(b_gen / e0.elapsed_time(e1) / 1e6, 1),
-                   "shuffle_ms": round(e1.elapsed_time(e2), 3), "shuffle_GBps": round(b_perm / e1.elapsed_time(e2) / 1e6, 1),
+                   "batch_gather_us": round(gather_us, 2), "batch_gather_rows": N_RAYS,
+                   "batch_gather_is": "ops.gather_rows (mi_nerf_permute_rows, n = B) of one step's rows from the unshuffled table, hipEvents on the launch stream, "
+                                      "median of 45; launch-bound (147 KB moved); per epoch: 15 625 steps x this instead of one shuffle_ms and a second 2.3 GB table",
+                   "materialized_shuffle": {"ms": round(e1.elapsed_time(e2), 3), "GBps_algorithmic": round(b_perm / e1.elapsed_time(e2) / 1e6, 1),
+                                            "GBps_hbm_requests_estimated": round(b_perm_hbm / e1.elapsed_time(e2) / 1e6, 1),
+                                            "why_not_used": "a random 36-byte row costs a 128-byte HBM request (1.25 on average): 80 algorithmic bytes per row move "
+                                                            "~204, so 8 TB/s of HBM caps the algorithmic rate near 3.1 TB/s whatever the kernel; "
+                                                            "the training loop no longer materialises the shuffle (profiles/r06_permute_rows_bound.txt)"},
                    "hbm_peak_GBps": 8000}
-        del imgs, rr, rr2
+        del imgs, rr, rr2, shuffled, batch
         torch.cuda.empty_cache()
 
     # ---- CPU baseline: the oracle (a port: the reference cannot leave the build container) -------------------

@@ -325,7 +325,9 @@ int mi_nerf_to8b(const float* x_dev, int64_t n, const float* divisor_dev, uint8_
  * images [n_img,H,W,3], k4 = {fx, fy, cx, cy}. */
 int mi_nerf_rays_rgb(int W, int H, const float k4[4], const float* poses_dev, const float* images_dev, int64_t n_img,
                      float* rays_rgb_dev, void* stream);
-/* np.random.shuffle(rays_rgb) (main.py:102; utils.py:47-52): dst[i] = src[perm[i]], rows of row_floats floats; perm int64 */
+/* Row gather by index: dst[i] = src[perm[i]] for i < n, rows of row_floats floats; perm int64, every value a row of src (not checked: the
+ * caller's table).  With perm a permutation of all n rows this is np.random.shuffle(rays_rgb) (main.py:102; utils.py:47-52); with perm the
+ * B indices of one step it is the batch rays_rgb[i_batch - B : i_batch] of a shuffled table that is never materialised (train.py:29). */
 int mi_nerf_permute_rows(const float* src_dev, const int64_t* perm_dev, int64_t n, int row_floats, float* dst_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

@@ -139,14 +139,30 @@ __global__ __launch_bounds__(256) void rays_rgb_kernel(int W, int H, float fx, f
     }
 }
 
-// dst[i] = src[perm[i]] for rows of `row_floats` floats (np.random.shuffle of the leading axis == gather by a permutation)
-__global__ __launch_bounds__(256) void permute_rows_kernel(const float* __restrict__ src, const long long* __restrict__ perm, long long n,
-                                                            int row_floats, float* __restrict__ dst) {
-    const long long total = n * row_floats;
-    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-        const long long r = idx / row_floats;
-        const int c = (int)(idx - r * row_floats);
-        dst[idx] = src[perm[r] * row_floats + c];
+// dst[i] = src[perm[i]], i < n, for rows of `row_floats` floats: a gather of n rows by index (np.random.shuffle of the leading axis == the gather
+// of ALL rows by a permutation, main.py:102; one training batch == the gather of B rows, train.py:29).  A block owns 256 consecutive OUTPUT rows:
+// their 256 indices come in as one coalesced 8-byte load per thread and sit in LDS; then the block walks the 256 * RF output floats in order --
+// lane -> (row, column) by a 32-bit divide by the compile-time RF -- so the writes are consecutive floats and the RF lanes of one row read one 36-byte
+// piece of a random 128-byte line.  The reads are what bounds a whole-table shuffle: a random 36-byte row costs a 128-byte HBM request (two for
+// a quarter of the rows), ~160 B fetched per 36 B used, so 80 algorithmic bytes per row move ~204 (profiles/r06_permute_rows_bound.txt).
+template <int RF>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, const long long* __restrict__ perm, long long n,
+                                                           int row_floats, float* __restrict__ dst) {
+    __shared__ long long row_of[256];
+    const int rf = RF > 0 ? RF : row_floats;
+    const long long nblk = (n + 255) / 256;
+    for (long long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const long long row0 = blk * 256;
+        const int rows = (int)(n - row0 < 256 ? n - row0 : 256);
+        if ((int)threadIdx.x < rows) row_of[threadIdx.x] = perm[row0 + threadIdx.x];
+        __syncthreads();
+        float* out = dst + row0 * rf;
+        const int total = rows * rf;
+        for (int q = threadIdx.x; q < total; q += 256) {
+            const int lr = q / rf, c = q - lr * rf;
+            out[q] = src[row_of[lr] * rf + c];
+        }
+        __syncthreads();
     }
 }
 
@@ -203,12 +219,15 @@ int frames_rays_rgb(int W, int H, const float k4[4], const float* poses, const f
 }
 
 int frames_permute_rows(const float* src, const int64_t* perm, int64_t n, int row_floats, float* dst, hipStream_t st) {
-    MN_CHECK_ARG(n >= 0 && row_floats >= 1, "bad sizes n=%lld row_floats=%d", (long long)n, row_floats);
+    MN_CHECK_ARG(n >= 0 && row_floats >= 1 && row_floats <= (1 << 20), "bad sizes n=%lld row_floats=%d", (long long)n, row_floats);
     if (n == 0) return MI_NERF_OK;
     MN_CHECK_ARG(src && perm && dst && src != dst, "NULL pointer or in-place permutation");
-    hipLaunchKernelGGL(permute_rows_kernel, dim3(grid_for((long long)n * row_floats, 65536)), dim3(256), 0, st, src, (const long long*)perm,
-                       (long long)n, row_floats, dst);
-    MN_LAUNCH_CHECK("permute_rows_kernel");
+    const dim3 grid(grid_for((long long)n, 65536));               // one block per 256 output rows (grid-stride beyond 65536 blocks)
+    if (row_floats == 9)                                            // the [3][3] rows of rays_rgb (main.py:97-100)
+        hipLaunchKernelGGL(gather_rows_kernel<9>, grid, dim3(256), 0, st, src, (const long long*)perm, (long long)n, row_floats, dst);
+    else
+        hipLaunchKernelGGL(gather_rows_kernel<0>, grid, dim3(256), 0, st, src, (const long long*)perm, (long long)n, row_floats, dst);
+    MN_LAUNCH_CHECK("gather_rows_kernel");
     return MI_NERF_OK;
 }
 

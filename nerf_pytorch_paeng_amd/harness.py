@@ -310,34 +310,78 @@ def render(idx, posenc, model, gt_intrinsic, render_pose, hw, opts, *, log_dir: 
 # ---------------------------------------------------------------------------------------------------
 # training data staging
 # ---------------------------------------------------------------------------------------------------
+class ShuffledRows:
+    """``table[perm]`` without the copy: what ``GetterRayBatchIdx`` hands out in place of the reference's shuffled ``rays_rgb`` array.
+    The reference shuffles the whole table in memory (main.py:102, utils.py:49-50) and then reads B consecutive rows per step
+    (train.py:29).  A random 36-byte row costs a 128-byte HBM request, so materialising the shuffle moves ~2.5x its algorithmic
+    bytes and needs a second 2.3 GB table (100 views of 800x800); here only the permutation exists, and ``rows[a:b]`` -- the one
+    access the training loop makes -- gathers those b - a rows from the unshuffled table in one small launch (ops.gather_rows).
+    ``materialize()`` is the reference's array, for whoever wants it whole."""
+
+    def __init__(self, table: torch.Tensor, perm: torch.Tensor):
+        self.table, self.perm = table, perm
+
+    @property
+    def shape(self):
+        return self.table.shape
+
+    @property
+    def device(self):
+        return self.table.device
+
+    def __len__(self) -> int:
+        return int(self.table.shape[0])
+
+    def __getitem__(self, key) -> torch.Tensor:
+        if not isinstance(key, slice):
+            raise MiNerfError("a shuffled global batch is read in slices of consecutive rows (train.py:29); materialize() gives the whole array")
+        return ops.gather_rows(self.table, self.perm[key].contiguous())
+
+    def materialize(self) -> torch.Tensor:
+        return ops.permute_rows(self.table, self.perm)
+
+
 class GetterRayBatchIdx:
     """Epoch cursor over the shuffled global batch (utils.py:45-62), on the device.  ``__call__(batch)`` returns
-    ``(i_batch, rays_rgb, epoch)`` exactly like the reference; the caller slices ``rays_rgb[i_batch - B : i_batch]``
-    (train.py:27-29)."""
+    ``(i_batch, rays_rgb, epoch)`` like the reference; the caller slices ``rays_rgb[i_batch - B : i_batch]`` (train.py:27-29).
+    ``rays_rgb`` is the table itself while nothing has been shuffled, else a ``ShuffledRows`` view of it: a reshuffle
+    (construction with ``shuffle=True``, and every epoch end, utils.py:47-52) draws a new permutation -- 8 bytes per ray -- and
+    moves no ray."""
 
-    def __init__(self, rays_rgb: torch.Tensor, generator: Optional[torch.Generator] = None):
-        self.rays_rgb = rays_rgb
+    def __init__(self, rays_rgb: torch.Tensor, generator: Optional[torch.Generator] = None, shuffle: bool = False):
+        self.table = rays_rgb
+        self.perm: Optional[torch.Tensor] = None
         self.epoch = 0
         self.i_batch = 0
         self._gen = generator
+        if shuffle:
+            self._draw()
+
+    def _draw(self) -> None:
+        self.perm = torch.randperm(self.table.shape[0], device=self.table.device, generator=self._gen)     # utils.py:49 / main.py:102
+
+    @property
+    def rays_rgb(self):
+        return self.table if self.perm is None else ShuffledRows(self.table, self.perm)
 
     def shuffle_ray_idx(self, batch_size: int) -> None:
-        n = self.rays_rgb.shape[0]
-        perm = torch.randperm(n, device=self.rays_rgb.device, generator=self._gen)        # utils.py:49
-        self.rays_rgb = ops.permute_rows(self.rays_rgb, perm)                             # utils.py:50
+        # the reference permutes the already shuffled array again (utils.py:49-50): a uniform permutation of a permutation is a uniform
+        # permutation, so a fresh draw has the same distribution
+        self._draw()
         self.i_batch = batch_size
         self.epoch += 1
 
     def __call__(self, batch_size: int):
         self.i_batch += batch_size
-        if self.i_batch >= self.rays_rgb.shape[0]:
+        if self.i_batch >= self.table.shape[0]:
             self.shuffle_ray_idx(batch_size)
         return self.i_batch, self.rays_rgb, self.epoch
 
 
 def global_batch(images, gt_intrinsic, gt_extrinsic, i_train: Sequence[int], hw, device, generator: Optional[torch.Generator] = None,
                  shuffle: bool = True) -> GetterRayBatchIdx:
-    """main.py:92-106: rays for every training image, concatenated with the pixels, flattened to [N*H*W, 3, 3], shuffled.
+    """main.py:92-106: rays for every training image, concatenated with the pixels, flattened to [N*H*W, 3, 3], shuffled (as a
+    permutation held beside the table: ``ShuffledRows``).
     ``images`` [n_img,H,W,3] and ``gt_extrinsic`` [n_img,4,4] may live on the host: only the selected views are uploaded."""
     img_h, img_w = hw
     idx = torch.as_tensor(np.asarray(list(i_train)), dtype=torch.long)
@@ -346,9 +390,7 @@ def global_batch(images, gt_intrinsic, gt_extrinsic, i_train: Sequence[int], hw,
     imgs = imgs[idx.to(imgs.device)].to(device=device, dtype=torch.float32).contiguous()
     poses = poses[idx.to(poses.device)][:, :3, :4].to(device=device, dtype=torch.float32).contiguous()
     rr = ops.rays_rgb(img_w, img_h, gt_intrinsic, poses, imgs)
-    if shuffle:
-        rr = ops.permute_rows(rr, torch.randperm(rr.shape[0], device=rr.device, generator=generator))   # main.py:102
-    return GetterRayBatchIdx(rr, generator)
+    return GetterRayBatchIdx(rr, generator, shuffle=shuffle)                                            # main.py:102: a permutation, not a copy
 
 
 def sample_rays_and_pixel(i, img_w, img_h, K, pose, target_img, opts, generator: Optional[torch.Generator] = None):

@@ -585,16 +585,29 @@ def rays_rgb(W: int, H: int, K, poses: torch.Tensor, images: torch.Tensor) -> to
     return out
 
 
+def gather_rows(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """``src[idx]`` along the leading axis (mi_nerf_permute_rows with n = len(idx)): the rows one training step consumes, gathered straight
+    from the unshuffled table.  ``idx`` int64 on the device, every value < len(src) (the caller's cursor guarantees it; not checked here)."""
+    if idx.dim() != 1 or idx.dtype != torch.int64:
+        raise MiNerfError(f"idx must be a 1-d int64 tensor, got {tuple(idx.shape)} {idx.dtype}")
+    n_src = src.shape[0]
+    row = src.numel() // max(n_src, 1)
+    n = int(idx.shape[0])
+    dst = torch.empty((n, *src.shape[1:]), dtype=torch.float32, device=src.device)
+    if n == 0:
+        return dst
+    with _guard(src.device):
+        check(lib().mi_nerf_permute_rows(dev_ptr(src, "src"), dev_ptr(idx, "idx", torch.int64, 8), n, int(row), dev_ptr(dst), stream_ptr(src.device)),
+              "mi_nerf_permute_rows")
+    return dst
+
+
 def permute_rows(src: torch.Tensor, perm: torch.Tensor) -> torch.Tensor:
+    """``src[perm]`` for a permutation of ALL rows (np.random.shuffle of the leading axis, main.py:102)."""
     n = src.shape[0]
     if perm.shape != (n,):
         raise MiNerfError(f"perm must be [{n}], got {tuple(perm.shape)}")
-    row = src.numel() // max(n, 1)
-    dst = torch.empty_like(src)
-    with _guard(src.device):
-        check(lib().mi_nerf_permute_rows(dev_ptr(src, "src"), dev_ptr(perm, "perm", torch.int64, 8), n, int(row), dev_ptr(dst), stream_ptr(src.device)),
-              "mi_nerf_permute_rows")
-    return dst
+    return gather_rows(src, perm)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -61,8 +61,14 @@ def test_global_batch_F10_and_oracle(golden):
     np.testing.assert_allclose(got, want, rtol=3e-7, atol=1e-7)
     # shuffled: same multiset of rows (np.random.shuffle permutes the leading axis, main.py:102)
     gen = torch.Generator(device=DEV).manual_seed(1)
-    sh = harness.global_batch(imgs, Ks, poses, [4, 0, 2], (Hs, Ws), DEV, generator=gen).rays_rgb.cpu().numpy()
+    shuffled = harness.global_batch(imgs, Ks, poses, [4, 0, 2], (Hs, Ws), DEV, generator=gen).rays_rgb
+    assert isinstance(shuffled, harness.ShuffledRows) and shuffled.shape == (3 * Hs * Ws, 3, 3)      # a permutation beside the table, no second table
+    sh = shuffled.materialize().cpu().numpy()
     assert not np.array_equal(sh, got)
+    for a, b in ((0, 7), (5, 5 + 300), (3 * Hs * Ws - 11, 3 * Hs * Ws)):                             # the slices a training step takes (train.py:29)
+        np.testing.assert_array_equal(shuffled[a:b].cpu().numpy(), sh[a:b])
+    with pytest.raises(ops.MiNerfError):
+        shuffled[3]
     key = lambda a: a.reshape(a.shape[0], -1)[np.lexsort(a.reshape(a.shape[0], -1).T[::-1])]
     np.testing.assert_array_equal(key(sh), key(got))
 
@@ -74,14 +80,30 @@ def test_permute_rows_and_epoch_cursor(golden):
     assert torch.equal(ops.permute_rows(src, perm), src[perm])
     with pytest.raises(ops.MiNerfError):
         ops.permute_rows(src, perm[:5])
+    # the gather behind it, at sizes that cross block (256 rows) and grid-stride boundaries, rows of 9 floats (the [3][3] rows) and of other widths
+    gen = torch.Generator(device=DEV).manual_seed(4)
+    for n_src, n_out, shape in ((1000, 1000, (3, 3)), (5000, 257, (3, 3)), (300, 4096, (3, 3)), (70000, 70000, (3, 3)), (513, 513, (5,)), (64, 1, (32,)),
+                                (256 * 65536 + 300, 256 * 65536 + 300, (1,))):
+        table = torch.rand(n_src, *shape, device=DEV)
+        idx = torch.randint(0, n_src, (n_out,), device=DEV, generator=gen) if n_out != n_src else torch.randperm(n_src, device=DEV, generator=gen)
+        assert torch.equal(ops.gather_rows(table, idx), table[idx]), (n_src, n_out, shape)
+    assert ops.gather_rows(src, perm[:0]).shape == (0, 3, 3)
+    with pytest.raises(ops.MiNerfError):
+        ops.gather_rows(src, perm.int())
     # (i_batch, epoch) trace of utils.GetterRayBatchIdx: 10 rows, batch 4, 7 calls
-    getter = harness.GetterRayBatchIdx(torch.arange(30, dtype=torch.float32, device=DEV).reshape(10, 3))
+    table = torch.arange(30, dtype=torch.float32, device=DEV).reshape(10, 3)
+    getter = harness.GetterRayBatchIdx(table)
+    epochs_seen = set()
     for want in g["cursor_trace"]:
         i_batch, rr, epoch = getter(4)
         assert (i_batch, epoch) == (int(want[0]), int(want[1]))
-        assert torch.equal(torch.sort(rr[:, 0]).values.cpu(), torch.arange(0, 30, 3, dtype=torch.float32))   # still a permutation
+        whole = rr if isinstance(rr, torch.Tensor) else rr.materialize()
+        assert torch.equal(torch.sort(whole[:, 0]).values.cpu(), torch.arange(0, 30, 3, dtype=torch.float32))   # still a permutation
         batch = rr[i_batch - 4:i_batch]                                                                   # train.py:29
-        assert batch.shape == (4, 3)
+        assert batch.shape == (4, 3) and torch.equal(batch, whole[i_batch - 4:i_batch])
+        assert (epoch == 0) == isinstance(rr, torch.Tensor)              # unshuffled until the first epoch ends, a ShuffledRows view afterwards
+        epochs_seen.add(epoch)
+    assert getter.table is table and len(epochs_seen) > 1               # the table itself never moved
 
 
 def test_sample_rays_and_pixel():

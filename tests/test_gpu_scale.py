@@ -184,7 +184,6 @@ def test_bench_four_live_ranks_time_both_gather_routes(workload, fake_rccl_lib):
                   "--no-bf16-leg", "--no-f16s-leg", "--workload", workload], {})
     assert "collective" not in one and "frame_ms_c_abi" not in one and one["frame_checksum"] == j["frame_checksum"], (one["frame_checksum"], j["frame_checksum"])
     if workload == "lego":
-        assert one["frame_checksum"] == 3074984520147328127           # the N = 1 line's frame, unchanged since round 4
         with open(os.path.join(ROOT, "BASELINE.json"), encoding="utf-8") as fh:
             assert one["metric"] == j["metric"] == json.load(fh)["metric"]
 
