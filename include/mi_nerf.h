@@ -20,9 +20,25 @@
 extern "C" {
 #endif
 
-#define MI_NERF_ABI_VERSION 3   /* 2: mi_nerf_render_cfg grew seed / reserved / ray_offset (in-kernel jitter)
+#define MI_NERF_ABI_VERSION 4   /* 2: mi_nerf_render_cfg grew seed / reserved / ray_offset (in-kernel jitter)
                                    3: mi_nerf_wgrad_product removed, mi_nerf_wgrad_products takes narrow products and needs
-                                      mi_nerf_wgrad_scratch_bytes(); the RCCL tile-gather helpers (mi_nerf_comm_*, mi_nerf_all_gather_tiles) */
+                                      mi_nerf_wgrad_scratch_bytes(); the RCCL tile-gather helpers (mi_nerf_comm_*, mi_nerf_all_gather_tiles)
+                                   4: mi_nerf_render_cfg.use_bf16 is called what it is, `mode` (MI_NERF_MODE_*; same offset, same values: a v3
+                                      caller's struct is read unchanged, and C11 / C++ callers keep the old member name for this one version);
+                                      MI_NERF_MODE_F16S_BF16; mi_nerf_permute_rows documented as the row gather it is (n = rows of dst) */
+
+/* Precision mode of an MLP launch (mi_nerf_render_cfg.mode, mi_nerf_time_mlp_rays): which kernel family evaluates the networks, and
+ * therefore which packer made the blobs handed in. */
+#define MI_NERF_MODE_F32 0          /* fp32 MFMA (default): blobs of mi_nerf_pack_weights                                              */
+#define MI_NERF_MODE_BF16 1         /* bf16 MFMA, launch shape chosen per launch: blobs of mi_nerf_pack_weights_bf16                   */
+#define MI_NERF_MODE_BF16_64 2      /* ... 64 points per wave pinned (A/B measurements)                                               */
+#define MI_NERF_MODE_BF16_32 3      /* ... 32 points per wave pinned                                                                  */
+                                    /* 4: retired (an 8-wave launch shape that was measured and removed); refused                      */
+#define MI_NERF_MODE_F16S 5         /* f16 split precision, fp32-grade results: blobs of mi_nerf_pack_weights_f16s                     */
+#define MI_NERF_MODE_F16S_BF16 6    /* mi_nerf_render_rays only: COARSE network in f16 split precision (packed_coarse from
+                                       mi_nerf_pack_weights_f16s), FINE network in bf16 (packed_fine from mi_nerf_pack_weights_bf16):
+                                       the fine sample positions come out fp32-grade, the 3/4 of the evaluations that the fine network
+                                       makes run at the bf16 rate                                                                     */
 
 /* status codes */
 #define MI_NERF_OK 0
@@ -199,9 +215,14 @@ typedef struct mi_nerf_render_cfg {
     float near_, far_;     /* opts.near / opts.far   (nerf_process.py:44,47) */
     int32_t Sc, Nf;        /* opts.N_samples_c / _f  (config.py:72-73)       */
     int32_t det;           /* opts.perturb == 0.     (nerf_process.py:65)    */
-    int32_t use_bf16;      /* 0: fp32 MFMA (default); 1: bf16 MFMA variant, launch shape chosen per launch;
-                              2 / 3: bf16 with 64 / 32 points per wave pinned (A/B measurements);
-                              5: f16 split precision (mi_nerf_mlp_rays_f16s; blobs from mi_nerf_pack_weights_f16s) */
+#if defined(__cplusplus) || (defined(__STDC_VERSION__) && __STDC_VERSION__ >= 201112L)
+    union {
+        int32_t mode;      /* MI_NERF_MODE_*                                                        */
+        int32_t use_bf16;  /* the member's name up to ABI 3 (same storage); goes away with ABI 5    */
+    };
+#else
+    int32_t mode;          /* MI_NERF_MODE_*  (C99: no anonymous union, so no alias for the old name) */
+#endif
     uint32_t seed;         /* in-kernel jitter (t_rand / u NULL): generator seed ...             */
     uint32_t reserved;     /* must be 0                                                          */
     int64_t ray_offset;    /* ... and the GLOBAL index of ray 0 (chunk / shard invariant frames) */
@@ -362,7 +383,7 @@ int mi_nerf_unpad_tiles(const float* staging_dev, int world, int H, int W, int C
  * kernel on `stream`, measured with hipEvents recorded on that same stream (torch.cuda.Event only sees
  * torch's current stream).  Synchronises the stream. */
 int mi_nerf_time_mlp_rays(const mi_nerf_net* net, const void* packed_dev, const float* rays_dev, const float* z_dev,
-                          int64_t n_rays, int S, float* raw_dev, int iters, int use_bf16, float* avg_ms_out,
+                          int64_t n_rays, int S, float* raw_dev, int iters, int mode, float* avg_ms_out,
                           void* stream);
 
 /* MFMA fragment-layout self test: runs a 32x32x(2k) product through the kernel's operand maps with

@@ -67,11 +67,9 @@ int pack_bwd_f16s(const mi_nerf_net*, const mi_nerf_params*, void*, size_t);
 size_t pack_map_bwd_f16s_len(const mi_nerf_net*);
 int pack_map_bwd_f16s(const mi_nerf_net*, int32_t*, size_t);
 int pack_apply_bwd_f16s(const mi_nerf_net*, const int32_t*, const float*, void*, size_t, unsigned*, hipStream_t);
-// the MLP launch of a given precision mode (mi_nerf_render_cfg.use_bf16 / mi_nerf_time_mlp_rays): 0 fp32 MFMA; 1..4 bf16 (launch shape);
-// 5 f16 split precision (fp32-grade results on the f16 matrix pipe, mlp_f16s.hip)
-#define MI_NERF_MODE_F16S 5
-// use_bf16 of mi_nerf_render_cfg / mi_nerf_time_mlp_rays -> launch shape of the bf16 kernel (0: chosen per launch)
-static inline int bf16_points_per_wave(int use_bf16) { return use_bf16 == 2 ? 64 : (use_bf16 == 3 ? 32 : (use_bf16 == 4 ? 832 : 0)); }
+// MI_NERF_MODE_* (mi_nerf_render_cfg.mode / mi_nerf_time_mlp_rays) -> launch shape of the bf16 kernel (0: chosen per launch)
+static inline int bf16_points_per_wave(int mode) { return mode == MI_NERF_MODE_BF16_64 ? 64 : (mode == MI_NERF_MODE_BF16_32 ? 32 : (mode == 4 ? 832 : 0)); }
+static inline bool mode_is_bf16(int mode) { return mode >= MI_NERF_MODE_BF16 && mode <= 4; }
 int wgrad_products(int, const float* const*, const int*, const int*, const float* const*, const int*, const int*, int64_t, float* const*, const int*,
                    float* const*, void*, size_t, hipStream_t, bool);
 int mlp_rays_fp32_stash(const mi_nerf_net*, const void*, const float*, const float*, int64_t, int, float*, float*, float*, float*, unsigned*,
@@ -429,17 +427,21 @@ int mi_nerf_render_rays(const mi_nerf_net* net, const void* packed_c, const void
     const int Sc = cfg->Sc, St = cfg->Sc + cfg->Nf;
     // 1-a) stratified depths; 2-a) coarse net; 3-a) composite          (nerf_process.py:187-198)
     // t_rand / u NULL: the jitter is drawn inside the consuming kernels (cfg->seed, cfg->ray_offset + ray, sample)
-    MN_CHECK_ARG(cfg->use_bf16 >= 0 && cfg->use_bf16 <= MI_NERF_MODE_F16S, "use_bf16 must be 0..5 (got %d)", cfg->use_bf16);
-    const int ppw = bf16_points_per_wave(cfg->use_bf16);
-    const bool f16s = cfg->use_bf16 == MI_NERF_MODE_F16S;
-    if (cfg->use_bf16 && !f16s) {
+    MN_CHECK_ARG(cfg->mode >= MI_NERF_MODE_F32 && cfg->mode <= MI_NERF_MODE_F16S_BF16, "mode must be one of MI_NERF_MODE_* (0..6; got %d)", cfg->mode);
+    const int ppw = bf16_points_per_wave(cfg->mode);
+    // per network: which kernel family evaluates it (MI_NERF_MODE_F16S_BF16: coarse in split precision, fine in bf16)
+    const bool coarse_f16s = cfg->mode == MI_NERF_MODE_F16S || cfg->mode == MI_NERF_MODE_F16S_BF16;
+    const bool fine_f16s = cfg->mode == MI_NERF_MODE_F16S;
+    const bool coarse_bf16 = mode_is_bf16(cfg->mode);
+    const bool fine_bf16 = mode_is_bf16(cfg->mode) || cfg->mode == MI_NERF_MODE_F16S_BF16;
+    if (coarse_bf16) {
         // the bf16 kernel draws the stratified depths in its own prologue and writes z_c (one launch fewer: at a 512-ray shard a
         // launch is ~4 us of a ~130 us step)
         const StratDraw sd{cfg->near_, cfg->far_, t_rand, cfg->seed, cfg->ray_offset, z_c};
         if (int rc = mlp_rays_bf16(net, packed_c, rays, nullptr, n, Sc, raw_c, st, ppw, &sd)) return rc;
     } else {
         if (int rc = stage_stratified(n, Sc, cfg->near_, cfg->far_, t_rand, cfg->seed, cfg->ray_offset, z_c, st)) return rc;
-        if (int rc = f16s ? mlp_rays_f16s(net, packed_c, rays, z_c, n, Sc, raw_c, st) : mlp_rays_fp32(net, packed_c, rays, z_c, n, Sc, raw_c, st)) return rc;
+        if (int rc = coarse_f16s ? mlp_rays_f16s(net, packed_c, rays, z_c, n, Sc, raw_c, st) : mlp_rays_fp32(net, packed_c, rays, z_c, n, Sc, raw_c, st)) return rc;
     }
     if (cfg->Nf == 0) return stage_composite(raw_c, z_c, rays, 6, n, Sc, rgb_c, disp_c, nullptr, wts_c, nullptr, st);
     {
@@ -448,26 +450,27 @@ int mi_nerf_render_rays(const mi_nerf_net* net, const void* packed_c, const void
         float* raw_f = (float*)(w + L.raw_f);
         if (int rc = stage_composite_fine_z(raw_c, z_c, rays, n, Sc, cfg->Nf, cfg->det, u, cfg->seed, cfg->ray_offset, rgb_c, disp_c, wts_c, z_f, st))
             return rc;
-        if (int rc = f16s ? mlp_rays_f16s(net, packed_f, rays, z_f, n, St, raw_f, st)
-                          : cfg->use_bf16 ? mlp_rays_bf16(net, packed_f, rays, z_f, n, St, raw_f, st, ppw, nullptr)
-                                          : mlp_rays_fp32(net, packed_f, rays, z_f, n, St, raw_f, st)) return rc;
+        if (int rc = fine_f16s ? mlp_rays_f16s(net, packed_f, rays, z_f, n, St, raw_f, st)
+                          : fine_bf16 ? mlp_rays_bf16(net, packed_f, rays, z_f, n, St, raw_f, st, ppw, nullptr)
+                                      : mlp_rays_fp32(net, packed_f, rays, z_f, n, St, raw_f, st)) return rc;
         if (int rc = stage_composite(raw_f, z_f, rays, 6, n, St, rgb_f, disp_f, nullptr, nullptr, nullptr, st)) return rc;
     }
     return MI_NERF_OK;
 }
 
 int mi_nerf_time_mlp_rays(const mi_nerf_net* net, const void* packed, const float* rays, const float* z, int64_t n_rays, int S,
-                          float* raw, int iters, int use_bf16, float* avg_ms, void* stream) {
+                          float* raw, int iters, int mode, float* avg_ms, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     MN_CHECK_ARG(iters >= 1 && avg_ms, "bad iters / NULL output");
+    MN_CHECK_ARG(mode >= MI_NERF_MODE_F32 && mode <= MI_NERF_MODE_F16S, "mode must be MI_NERF_MODE_F32 .. MI_NERF_MODE_F16S: one network, one kernel family (got %d)", mode);
     hipEvent_t e0, e1;
     MN_HIP(hipEventCreate(&e0));
     MN_HIP(hipEventCreate(&e1));
     int rc = MI_NERF_OK;
     MN_HIP(hipEventRecord(e0, st));
     for (int i = 0; i < iters && rc == MI_NERF_OK; ++i)
-        rc = use_bf16 == MI_NERF_MODE_F16S ? mlp_rays_f16s(net, packed, rays, z, n_rays, S, raw, st)
-             : use_bf16 ? mlp_rays_bf16(net, packed, rays, z, n_rays, S, raw, st, bf16_points_per_wave(use_bf16), nullptr)
+        rc = mode == MI_NERF_MODE_F16S ? mlp_rays_f16s(net, packed, rays, z, n_rays, S, raw, st)
+             : mode ? mlp_rays_bf16(net, packed, rays, z, n_rays, S, raw, st, bf16_points_per_wave(mode), nullptr)
                         : mlp_rays_fp32(net, packed, rays, z, n_rays, S, raw, st);
     MN_HIP(hipEventRecord(e1, st));
     MN_HIP(hipEventSynchronize(e1));

@@ -204,7 +204,7 @@ def assemble_tiles(tiles: Sequence[torch.Tensor], H: int, W: int) -> torch.Tenso
 
 
 def render_shard(H: int, W: int, K, pose, model, opts, world: int, rank: int, *, seed: int = 0, bf16: bool = False,
-                 f16s: bool = False) -> torch.Tensor:
+                 f16s: bool = False, coarse_f16s: bool = False) -> torch.Tensor:
     """Rank ``rank``'s ``[rows_local * W, 4]`` tile (rgb + disp) of an H x W frame split over ``world`` ranks: rays generated on
     this device from (K, pose, row range), jitter keyed on the GLOBAL ray index (``ray_offset`` = first pixel of the block), the
     fine outputs when ``N_samples_f > 0`` else the coarse ones (test.py:42-47).  No communication."""
@@ -216,14 +216,15 @@ def render_shard(H: int, W: int, K, pose, model, opts, world: int, rank: int, *,
     _, d = ops.make_o_d(W, H, K, pose, packed.device, row0=r0, n_rows=nr, want_origins=False)
     p = pose if isinstance(pose, torch.Tensor) else torch.as_tensor(pose)
     o = p[:3, -1].to(packed.device, torch.float32).expand(d.shape)
-    rc, dc, rf, df = NP.batchify_rays_and_render_by_chunk(o, d, packed, None, H, W, K, opts, seed=seed, ray_offset=r0 * W, bf16=bf16, f16s=f16s)
+    rc, dc, rf, df = NP.batchify_rays_and_render_by_chunk(o, d, packed, None, H, W, K, opts, seed=seed, ray_offset=r0 * W, bf16=bf16, f16s=f16s,
+                                                          coarse_f16s=coarse_f16s)
     rgb, disp = (rc, dc) if int(opts.N_samples_f) == 0 else (rf, df)
     return torch.cat([rgb, disp[:, None]], -1)
 
 
 def render_frame(H: int, W: int, K, pose, model, opts, *, seed: int = 0, group=None, bf16: bool = False, f16s: bool = False,
                  render_rows_fn: Optional[Callable[[int, int], torch.Tensor]] = None, via: str = "torch",
-                 force_collective: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+                 force_collective: bool = False, coarse_f16s: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
     """Render one H x W frame sharded over the process group; returns (rgb [H,W,3], disp [H,W]) on every rank.
 
     Counterpart of the per-pose body of the reference's test()/render() harness (test.py:38-53,143-152):
@@ -236,7 +237,7 @@ def render_frame(H: int, W: int, K, pose, model, opts, *, seed: int = 0, group=N
     else:
         world, rank = 1, 0
     if render_rows_fn is None:
-        local = render_shard(H, W, K, pose, model, opts, world, rank, seed=seed, bf16=bf16, f16s=f16s)
+        local = render_shard(H, W, K, pose, model, opts, world, rank, seed=seed, bf16=bf16, f16s=f16s, coarse_f16s=coarse_f16s)
     else:
         local = render_rows_fn(*shard_rows(H, world, rank))
     full = gather_tiles(local, H, W, group, force_collective=force_collective, via=via)

@@ -197,11 +197,12 @@ def llff_cameras(raw_poses, raw_bds, bd_factor=.75, path_zflat: bool = False) ->
 # ---------------------------------------------------------------------------------------------------
 def _precision(opts) -> Dict[str, bool]:
     """``opts.precision`` (not a flag of the reference's config.py; absent = "fp32", the reference's arithmetic) selects the network's
-    precision mode for the eval / video harness: "fp32" | "f16s" (split precision: fp32-grade results, ~3x faster) | "bf16"."""
+    precision mode for the eval / video harness: "fp32" | "f16s" (split precision: fp32-grade results, ~3x faster) | "bf16" |
+    "f16s+bf16" (coarse network in split precision -- the fine sample positions are the fp32 path's -- fine network in bf16)."""
     mode = str(getattr(opts, "precision", "fp32")).lower()
-    if mode not in ("fp32", "f16s", "bf16"):
-        raise ValueError(f"opts.precision must be 'fp32', 'f16s' or 'bf16', got {mode!r}")
-    return {"bf16": mode == "bf16", "f16s": mode == "f16s"}
+    if mode not in ("fp32", "f16s", "bf16", "f16s+bf16"):
+        raise ValueError(f"opts.precision must be 'fp32', 'f16s', 'bf16' or 'f16s+bf16', got {mode!r}")
+    return {"bf16": mode in ("bf16", "f16s+bf16"), "f16s": mode == "f16s", "coarse_f16s": mode == "f16s+bf16"}
 
 
 def _frozen(model, opts):
@@ -210,7 +211,7 @@ def _frozen(model, opts):
     with a weight beyond the f16 range raises instead of rendering from a clipped network."""
     from .weights import packed_for
     packed = packed_for(model)
-    if _precision(opts)["f16s"]:
+    if _precision(opts)["f16s"] or _precision(opts)["coarse_f16s"]:
         packed.f16s()
         packed.check_f16s_range()
     return packed
@@ -236,28 +237,35 @@ def test(idx, i_test, posenc, model, test_imgs, gt_intrinsic, gt_extrinsic, hw, 
         os.makedirs(save_dir, exist_ok=True)
     img_h, img_w = hw
     dev = next(model.parameters()).device if isinstance(model, torch.nn.Module) else model.device
-    losses: List[float] = []
-    psnrs: List[float] = []
-    frames = []
+    n_pose = len(gt_extrinsic)
+    want_frames = save_dir is not None or keep_frames
+    # everything a frame produces stays on the device until the loop is over: [mse, psnr] per frame in one [N, 2] tensor, the uint8
+    # frames in two stacks -- ONE device -> host copy each after the last pose, no host synchronisation per frame
+    metrics = torch.empty(n_pose, 2, dtype=torch.float32, device=dev)
+    rgbs8 = torch.empty(n_pose, img_h, img_w, 3, dtype=torch.uint8, device=dev) if want_frames else None
+    disps8 = torch.empty(n_pose, img_h, img_w, 1, dtype=torch.uint8, device=dev) if want_frames else None
     with torch.no_grad():
         frozen = _frozen(model, opts)
         for i, pose in enumerate(gt_extrinsic):
             pose = as_f32_dev(pose, dev)
             pred_rgb, pred_disp = _render_pose(frozen, posenc, gt_intrinsic, pose, hw, opts)
             target = as_f32_dev(test_imgs[i], pred_rgb.device).reshape(-1, 3)             # test.py:63
-            m = ops.image_metrics(pred_rgb, target)                                       # img2mse, mse2psnr: test.py:65-67
-            rgb8 = ops.to8b(pred_rgb).reshape(img_h, img_w, 3)                            # test.py:55
-            disp8 = ops.to8b(pred_disp, ops.nanmax(pred_disp)).reshape(img_h, img_w, 1)   # test.py:56
-            mse, psnr = (float(v) for v in m.cpu())
-            losses.append(mse)
-            psnrs.append(psnr)
-            if save_dir is not None or keep_frames:
-                rgb_np, disp_np = rgb8.cpu().numpy(), disp8.cpu().numpy()
-                if save_dir is not None:
-                    write_png(os.path.join(save_dir, f"{i:03d}.png"), rgb_np)
-                    write_png(os.path.join(save_dir, f"{i:03d}_disp.png"), disp_np)
-                if keep_frames:
-                    frames.append((rgb_np, disp_np))
+            metrics[i] = ops.image_metrics(pred_rgb, target)                              # img2mse, mse2psnr: test.py:65-67
+            if want_frames:
+                rgbs8[i] = ops.to8b(pred_rgb).reshape(img_h, img_w, 3)                        # test.py:55
+                disps8[i] = ops.to8b(pred_disp, ops.nanmax(pred_disp)).reshape(img_h, img_w, 1)   # test.py:56
+    m_host = metrics.cpu().numpy()
+    losses: List[float] = [float(v) for v in m_host[:, 0]]
+    psnrs: List[float] = [float(v) for v in m_host[:, 1]]
+    frames = []
+    if want_frames:
+        rgbs_np, disps_np = rgbs8.cpu().numpy(), disps8.cpu().numpy()
+        for i in range(n_pose):
+            if save_dir is not None:
+                write_png(os.path.join(save_dir, f"{i:03d}.png"), rgbs_np[i])
+                write_png(os.path.join(save_dir, f"{i:03d}_disp.png"), disps_np[i])
+            if keep_frames:
+                frames.append((rgbs_np[i], disps_np[i]))
     best = int(np.argmax(psnrs)) if psnrs else -1
     res = {"loss": losses, "psnr": psnrs, "ssim": None, "lpips": None, "best_idx": best,
            "best_psnr": psnrs[best] if psnrs else None, "mean_psnr": float(np.mean(psnrs)) if psnrs else None}

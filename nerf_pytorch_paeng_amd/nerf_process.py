@@ -53,15 +53,6 @@ def _det(opts) -> bool:
     return isinstance(p, (int, float)) and p == 0.0
 
 
-def _enc_L(posenc, model_net) -> tuple:
-    """(L_x, L_d) from the posenc closures when they carry .L, else from the model shapes."""
-    try:
-        fx, fd = posenc
-        return int(fx.L), int(fd.L)
-    except Exception:
-        return model_net.L_x, model_net.L_d
-
-
 # --------------------------------------------------------------------------------------------------
 def ndc_rays(H, W, focal, near, rays_o, rays_d):
     """NDC warp for forward-facing scenes (nerf_process.py:8-28)."""
@@ -153,14 +144,14 @@ def run_network(model, embedded, is_fine: bool = False):
 
 # --------------------------------------------------------------------------------------------------
 def _render(rays: torch.Tensor, packed: PackedNeRF, opts, t_rand, u, seed: int, ray_offset: int, bf16: bool,
-            intermediates: bool, f16s: bool = False) -> Dict[str, torch.Tensor]:
+            intermediates: bool, f16s: bool = False, coarse_f16s: bool = False) -> Dict[str, torch.Tensor]:
     n = rays.shape[0]
     dev = rays.device
     Sc, Nf = int(opts.N_samples_c), int(opts.N_samples_f)
     det = _det(opts)
     # jitter: explicit tensors when the caller injects them (or wants them back); otherwise the kernels draw it themselves from the
     # same counter-based generator, keyed on (seed, ray_offset + ray, sample) -- identical values, no tensors, no extra launches
-    cfg = ops.render_cfg(float(opts.near), float(opts.far), Sc, Nf, det, bf16, seed=seed, ray_offset=ray_offset, f16s=f16s)
+    cfg = ops.render_cfg(float(opts.near), float(opts.far), Sc, Nf, det, bf16, seed=seed, ray_offset=ray_offset, f16s=f16s, coarse_f16s=coarse_f16s)
     if t_rand is not None:
         t_rand = as_f32_dev(t_rand, dev)
     elif intermediates:
@@ -172,7 +163,10 @@ def _render(rays: torch.Tensor, packed: PackedNeRF, opts, t_rand, u, seed: int, 
             u = ops.fill_uniform(seed, 1, ray_offset, n, Nf, dev)
     else:
         u = None
-    blobs = packed.f16s() if f16s else (packed.bf16() if bf16 else (packed.coarse, packed.fine))
+    if coarse_f16s:                                                 # MI_NERF_MODE_F16S_BF16: one blob of each family (both 256 wide)
+        blobs = (packed.f16s()[0], packed.bf16()[1])
+    else:
+        blobs = packed.f16s() if f16s else (packed.bf16() if bf16 else (packed.coarse, packed.fine))
     rgb_c, disp_c, rgb_f, disp_f, ws = ops.render_rays(packed.kernel_net(bf16, f16s), blobs[0], blobs[1] if Nf > 0 else None, cfg, rays, t_rand, u)
     out = {"rgb_c": rgb_c, "disp_c": disp_c}                        # nerf_process.py:215-216
     if Nf > 0:
@@ -185,10 +179,11 @@ def _render(rays: torch.Tensor, packed: PackedNeRF, opts, t_rand, u, seed: int, 
 
 
 def render_rays(rays, model, posenc, opts, *, t_rand=None, u=None, seed=None, ray_offset: int = 0, bf16: bool = False,
-                return_intermediates: bool = False, f16s: bool = False):
+                return_intermediates: bool = False, f16s: bool = False, coarse_f16s: bool = False):
     """Coarse pass -> composite -> resample -> fine pass (nerf_process.py:185-216) as one fused launch
     sequence.  Returns ``{'rgb_c','disp_c'[,'rgb_f','disp_f']}``.  ``bf16`` / ``f16s`` select the network's precision mode
-    (fp32 MFMA by default; bf16 MFMA; f16 split precision: fp32-grade results on the f16 matrix pipe)."""
+    (fp32 MFMA by default; bf16 MFMA; f16 split precision: fp32-grade results on the f16 matrix pipe); ``bf16`` with ``coarse_f16s``
+    evaluates the coarse network in split precision and the fine one in bf16 (the fine sample positions then match the fp32 path's)."""
     if train_path.wants_grad(model):
         if bf16 or return_intermediates:
             raise MiNerfError("the training path has no bf16 mode (fp32, or f16s=True: split-precision forward) and returns no intermediates")
@@ -199,11 +194,11 @@ def render_rays(rays, model, posenc, opts, *, t_rand=None, u=None, seed=None, ra
     rays = as_f32_dev(rays, packed.device)
     if rays.dim() != 2 or rays.shape[1] != 6:
         raise MiNerfError(f"rays must be [n, 6] (o, d), got {tuple(rays.shape)}")
-    return _render(rays, packed, opts, t_rand, u, _next_seed(seed), int(ray_offset), bf16, return_intermediates, f16s)
+    return _render(rays, packed, opts, t_rand, u, _next_seed(seed), int(ray_offset), bf16, return_intermediates, f16s, coarse_f16s)
 
 
 def batchify_rays_and_render_by_chunk(ray_o, ray_d, model, posenc, H, W, K, opts, *, t_rand=None, u=None, seed=None,
-                                      ray_offset: int = 0, bf16: bool = False, f16s: bool = False):
+                                      ray_offset: int = 0, bf16: bool = False, f16s: bool = False, coarse_f16s: bool = False):
     """Drop-in entry point (nerf_process.py:220-252): flatten, optional NDC warp for llff, render.
     Returns ``(rgb_c [N,3], disp_c [N], rgb_f [N,3] | None, disp_f [N] | None)``.
 
@@ -236,7 +231,7 @@ def batchify_rays_and_render_by_chunk(ray_o, ray_d, model, posenc, H, W, K, opts
             parts.append(train_path.render_train(rays[i:j].contiguous(), model, opts, t_rand=tr, u=uu, seed=seed,
                                                  ray_offset=int(ray_offset) + i, f16s=f16s))
         else:
-            parts.append(_render(rays[i:j], packed, opts, tr, uu, seed, int(ray_offset) + i, bf16, False, f16s))
+            parts.append(_render(rays[i:j], packed, opts, tr, uu, seed, int(ray_offset) + i, bf16, False, f16s, coarse_f16s))
     def cat(key):
         return parts[0][key] if len(parts) == 1 else torch.cat([p[key] for p in parts], dim=0)
     if Nf > 0:

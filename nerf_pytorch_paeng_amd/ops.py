@@ -613,18 +613,23 @@ def permute_rows(src: torch.Tensor, perm: torch.Tensor) -> torch.Tensor:
 # ------------------------------------------------------------------------------------------------
 # fused render
 # ------------------------------------------------------------------------------------------------
-BF16_SHAPES = {0: 1, 64: 2, 32: 3, 832: 4}          # points per wave (832: 8 waves of 32 per workgroup) -> mi_nerf_render_cfg.use_bf16
-MODE_F16S = 5                                       # mi_nerf_render_cfg.use_bf16 for the f16 split-precision variant
+# MI_NERF_MODE_* of include/mi_nerf.h (mi_nerf_render_cfg.mode, mi_nerf_time_mlp_rays)
+MODE_F32, MODE_BF16, MODE_BF16_64, MODE_BF16_32, MODE_F16S, MODE_F16S_BF16 = 0, 1, 2, 3, 5, 6
+BF16_SHAPES = {0: MODE_BF16, 64: MODE_BF16_64, 32: MODE_BF16_32, 832: 4}          # points per wave -> mode (832: a retired shape the library refuses)
 
 
 def render_cfg(near: float, far: float, Sc: int, Nf: int, det: bool, bf16: bool = False, points_per_wave: int = 0, seed: int = 0,
-               ray_offset: int = 0, f16s: bool = False) -> RenderCfg:
+               ray_offset: int = 0, f16s: bool = False, coarse_f16s: bool = False) -> RenderCfg:
     """``points_per_wave`` (bf16 only): 0 = the bf16 kernel's launch shape is chosen per launch; 64 / 32 pin it.
     ``f16s``: the split-precision MLP variant (blobs from PackedNeRF.f16s()).
+    ``bf16`` with ``coarse_f16s``: MI_NERF_MODE_F16S_BF16 -- the coarse network in split precision (fp32-grade fine sample positions),
+    the fine network in bf16; the caller hands PackedNeRF.f16s()[0] and PackedNeRF.bf16()[1].
     ``seed`` / ``ray_offset`` key the jitter the kernels draw themselves when render_rays gets no ``t_rand`` / ``u`` tensor."""
     if bf16 and f16s:
-        raise MiNerfError("bf16 and f16s are different precision modes: pick one")
-    mode = MODE_F16S if f16s else (BF16_SHAPES[int(points_per_wave)] if bf16 else 0)
+        raise MiNerfError("bf16 and f16s are different precision modes: pick one (bf16 with coarse_f16s=True mixes them per network)")
+    if coarse_f16s and (not bf16 or points_per_wave):
+        raise MiNerfError("coarse_f16s goes with bf16=True (fine network in bf16, launch shape chosen per launch)")
+    mode = MODE_F16S if f16s else (MODE_F16S_BF16 if coarse_f16s else (BF16_SHAPES[int(points_per_wave)] if bf16 else MODE_F32))
     return RenderCfg(float(near), float(far), int(Sc), int(Nf), int(bool(det)), mode, int(seed) & 0xFFFFFFFF, 0, int(ray_offset))
 
 

@@ -22,6 +22,12 @@ int main(void) {
     mi_nerf_render_cfg cfg;
     memset(&cfg, 0, sizeof cfg);
     cfg.near_ = 2.0f; cfg.far_ = 6.0f; cfg.Sc = 64; cfg.Nf = 128;
+    cfg.mode = MI_NERF_MODE_F32;                                                /* ABI 4: the member is called what it is */
+#if defined(__STDC_VERSION__) && __STDC_VERSION__ >= 201112L
+    cfg.use_bf16 = MI_NERF_MODE_BF16;                                           /* C11: the ABI 3 name is the same storage (one more version) */
+    EXPECT(cfg.mode == MI_NERF_MODE_BF16);
+    cfg.mode = MI_NERF_MODE_F32;
+#endif
     const size_t ws = mi_nerf_render_workspace_bytes(&cfg, 4096);
     EXPECT(ws > 20u * 1000 * 1000);                                             /* z_c, raw_c, weights_c, z_f, raw_f of 4096 rays */
     mi_nerf_workspace_layout lay;
@@ -30,6 +36,15 @@ int main(void) {
     /* argument errors: status + text, no exception, no GPU touched */
     EXPECT(mi_nerf_render_rays(&net, NULL, NULL, &cfg, NULL, 4096, NULL, NULL, NULL, 0, NULL, NULL, NULL, NULL, NULL) == MI_NERF_EINVAL);
     EXPECT(strlen(mi_nerf_last_error()) > 0);
+    {   /* a mode that does not exist is refused by name, before any pointer is looked at beyond NULL checks */
+        float rays[6] = {0, 0, 0, 0, 0, -1}, out[8];
+        char blob_stub[16], ws_stub[16];
+        mi_nerf_render_cfg bad = cfg;
+        bad.mode = 7; bad.Nf = 0; bad.Sc = 1;
+        EXPECT(mi_nerf_render_rays(&net, blob_stub, NULL, &bad, rays, 1, NULL, NULL, ws_stub, (size_t)1 << 20, out, out + 3, NULL, NULL, NULL) == MI_NERF_EINVAL);
+        EXPECT(strstr(mi_nerf_last_error(), "MI_NERF_MODE_") != NULL);
+        EXPECT(MI_NERF_MODE_F16S == 5 && MI_NERF_MODE_F16S_BF16 == 6 && MI_NERF_MODE_BF16_32 == 3);
+    }
     EXPECT(mi_nerf_composite(NULL, NULL, NULL, 6, 4, 64, NULL, NULL, NULL, NULL, NULL, NULL) == MI_NERF_EINVAL);
     void* comm = NULL;
     char id[MI_NERF_COMM_ID_BYTES];

@@ -22,7 +22,7 @@ OVERRIDES = {
     "mi_nerf_mlp_backward_mode": {10: 1 << 34, 12: 0, 13: 0},     # work_bytes, stage, mode
     "mi_nerf_mlp_embedded_backward": {8: 1 << 34},
     "mi_nerf_rays_rgb": {0: 8, 1: 8, 5: 2},            # W, H, n_img
-    "mi_nerf_time_mlp_rays": {7: 1, 8: 0},             # iters, use_bf16
+    "mi_nerf_time_mlp_rays": {7: 1, 8: 0},             # iters, mode
     "mi_nerf_fill_uniform": {4: 8},
     "mi_nerf_wgrad_products": {0: 1},
     "mi_nerf_wgrad_products_f16s": {0: 1},

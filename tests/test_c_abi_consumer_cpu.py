@@ -10,7 +10,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_header_compiles_as_c99_and_the_library_links_and_answers(tmp_path):
+@pytest.mark.parametrize("std", ["c99", "c11"])          # c11: mi_nerf_render_cfg keeps the ABI 3 member name `use_bf16` as an alias of `mode`
+def test_header_compiles_as_c99_and_the_library_links_and_answers(tmp_path, std):
     gcc = shutil.which("gcc")
     if gcc is None:
         pytest.skip("gcc not found")
@@ -18,7 +19,7 @@ def test_header_compiles_as_c99_and_the_library_links_and_answers(tmp_path):
     _lib.lib()                                           # builds / checks the library
     pkg = os.path.dirname(_lib.LIB_PATH)
     exe = str(tmp_path / "consumer")
-    r = subprocess.run([gcc, "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c_abi", "consumer.c"),
+    r = subprocess.run([gcc, f"-std={std}", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c_abi", "consumer.c"),
                         "-L", pkg, "-lmi_nerf", f"-Wl,-rpath,{pkg}", "-o", exe], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     # every entry the header declares is in the library's dynamic symbol table (a C linker needs nothing else)
@@ -27,4 +28,4 @@ def test_header_compiles_as_c99_and_the_library_links_and_answers(tmp_path):
         assert f" T {name}\n" in syms, name
     run = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert run.returncode == 0, run.stdout + run.stderr
-    assert "c_abi consumer ok: ABI 3" in run.stdout
+    assert "c_abi consumer ok: ABI 4" in run.stdout
