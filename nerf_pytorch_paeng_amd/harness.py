@@ -4,19 +4,20 @@
   checkpoint ingest (``model_state_dict`` of a reference ``.pth.tar``), one ``make_o_d`` +
   ``batchify_rays_and_render_by_chunk`` per pose, MSE/PSNR against ground truth, 8-bit frames.  Metrics and the
   8-bit conversion run as device kernels (``mi_nerf_image_metrics``, ``mi_nerf_nanmax``, ``mi_nerf_to8b``); the only
-  device->host copies are the finished uint8 frames and two floats per frame.  SSIM / LPIPS come from a third-party
+  device->host copies are the finished uint8 frames and two floats per frame, each copied ONCE after the last pose.  SSIM / LPIPS come from a third-party
   package the reference imports (IQA_pytorch) and are not part of this path: they are reported as ``None``.
-* ``global_batch`` / ``GetterRayBatchIdx`` -- the global-batch ray precompute and epoch shuffle (main.py:92-106,
-  utils.py:45-62) as one ray-generation launch over all training images and a device-side row permutation, instead
-  of numpy on the host followed by a 2.3 GB upload.
+* ``global_batch`` / ``GetterRayBatchIdx`` / ``ShuffledRows`` -- the global-batch ray precompute and epoch shuffle (main.py:92-106,
+  utils.py:45-62) as one ray-generation launch over all training images; the shuffle is a permutation held beside the table
+  and a step gathers its rows through it (no shuffled copy), instead of numpy on the host followed by a 2.3 GB upload.
 * ``sample_rays_and_pixel`` -- per-image ray/pixel sampling (rays.py:36-64); rays are generated for the selected
   pixels only.
-* ``get_render_pose`` / ``pose_spherical`` -- the 360-degree camera path (dataset/render_pose.py:28-43), built on the
-  host once and uploaded once.
-* ``normalize`` / ``viewmatrix`` / ``poses_avg`` / ``render_path_spiral`` / ``recenter_poses`` / ``llff_render_poses`` /
-  ``llff_cameras`` -- the forward-facing (LLFF) camera path (dataset/load_llff.py:151-204, 277-346): the spiral the
-  reference's loader hands to ``render()`` for ``data_type == 'llff'`` (main.py:43, test.py:125-145).  Host float64
-  numpy like the reference (120 poses of 15 numbers; one upload).
+* ``spherical_poses`` (and ``get_render_pose`` / ``pose_spherical`` on top of it) -- the 360-degree camera path
+  (dataset/render_pose.py:28-43): every pose of the path from one closed-form array expression, built on the host once and
+  uploaded once.
+* ``look_frames`` / ``rig_average`` / ``spiral_path`` / ``recenter_rig`` / ``llff_render_poses`` / ``llff_cameras`` -- the
+  forward-facing (LLFF) camera path (dataset/load_llff.py:151-204, 277-346): the spiral the reference's loader hands to
+  ``render()`` for ``data_type == 'llff'`` (main.py:43, test.py:125-145); all cameras of a path from batched array
+  operations (120 poses of 15 numbers; one upload).
 
 PNG output uses a 30-line zlib encoder (imageio, which the reference uses, is not a dependency of this path).
 """
@@ -80,110 +81,127 @@ def _ckpt_path(log_dir: str, exp_name: str, idx) -> str:
     return os.path.join(log_dir, exp_name, f"{exp_name}_{idx}.pth.tar")                 # test.py:20, train.py:112-114
 
 
+# ---------------------------------------------------------------------------------------------------
+# Camera paths, all poses of a path from one array expression (host side: a path is a few KB, built once and uploaded once).
+# ---------------------------------------------------------------------------------------------------
+def spherical_poses(theta_deg, phi_deg: float, radius: float) -> np.ndarray:
+    """Camera-to-world matrices [N, 4, 4] (fp32) of cameras on a sphere of ``radius`` around the origin, looking at it, at azimuths
+    ``theta_deg`` [N] and elevation ``phi_deg`` -- the closed form of the reference's matrix chain (dataset/render_pose.py:5-34:
+    translate by radius along z, rotate about x by phi, about y by theta, swap axes).  Every entry of that chain is ONE fp32 product
+    of fp32 sines / cosines (the other terms of each dot product are exact zeros), so writing the products out reproduces it bit
+    for bit (fixture F10) without a matrix multiply per pose:
+
+        c2w = [[-ct,  st*sp,  st*cp,  (st*cp)*r],
+               [ st,  ct*sp,  ct*cp,  (ct*cp)*r],
+               [  0,     cp,    -sp,      -sp*r],
+               [  0,      0,      0,          1]]
+    """
+    th = np.atleast_1d(np.asarray(theta_deg, dtype=np.float64)) / 180.0 * np.pi
+    ph = float(phi_deg) / 180.0 * np.pi
+    ct, st = np.cos(th).astype(np.float32), np.sin(th).astype(np.float32)
+    cp, sp, r = np.float32(np.cos(ph)), np.float32(np.sin(ph)), np.float32(radius)
+    zero, one = np.zeros_like(ct), np.ones_like(ct)
+    fwd = np.stack([st * cp, ct * cp, -sp * one], -1)                 # third column: where the camera sits, per unit radius
+    rows = np.stack([np.stack([-ct, st * sp, fwd[:, 0], fwd[:, 0] * r], -1),
+                     np.stack([st, ct * sp, fwd[:, 1], fwd[:, 1] * r], -1),
+                     np.stack([zero, cp * one, fwd[:, 2], fwd[:, 2] * r], -1),
+                     np.stack([zero, zero, zero, one], -1)], 1)
+    return rows.astype(np.float32)
+
+
 def pose_spherical(theta: float, phi: float, radius: float) -> torch.Tensor:
-    """dataset/render_pose.py:28-34 with the same fp32 matrix chain."""
-    def t32(rows):
-        return torch.tensor(np.array(rows), dtype=torch.float32)
-    trans = t32([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, radius], [0, 0, 0, 1]])
-    ph = phi / 180.0 * np.pi
-    rot_phi = t32([[1, 0, 0, 0], [0, np.cos(ph), -np.sin(ph), 0], [0, np.sin(ph), np.cos(ph), 0], [0, 0, 0, 1]])
-    th = theta / 180.0 * np.pi
-    rot_theta = t32([[np.cos(th), 0, -np.sin(th), 0], [0, 1, 0, 0], [np.sin(th), 0, np.cos(th), 0], [0, 0, 0, 1]])
-    c2w = rot_theta @ (rot_phi @ trans)
-    return t32([[-1, 0, 0, 0], [0, 0, 1, 0], [0, 1, 0, 0], [0, 0, 0, 1]]) @ c2w
+    """One pose of ``spherical_poses`` (dataset/render_pose.py:28-34) -> [4, 4]."""
+    return torch.from_numpy(spherical_poses([theta], phi, radius)[0])
 
 
 def get_render_pose(n_angle: int = 1, single_angle: float = -1, phi: float = -30.0, nf: float = 4.0, device=None) -> torch.Tensor:
-    """dataset/render_pose.py:37-43 -> [n, 4, 4]; uploaded once when ``device`` is given."""
-    if not n_angle == 1 and single_angle == -1:
-        poses = torch.stack([pose_spherical(a, phi, nf) for a in np.linspace(-180, 180, n_angle + 1)[:-1]], 0)
-    else:
-        poses = pose_spherical(single_angle, phi, nf).unsqueeze(0)
+    """The video path of blender / custom scenes (dataset/render_pose.py:37-43) -> [n, 4, 4]: ``n_angle`` azimuths evenly over the
+    circle starting at -180 degrees, or the one view ``single_angle`` when that is given (or when only one view is asked for).
+    Uploaded once when ``device`` is given."""
+    circle = n_angle != 1 and single_angle == -1
+    azimuths = np.linspace(-180, 180, n_angle + 1)[:-1] if circle else [single_angle]
+    poses = torch.from_numpy(spherical_poses(azimuths, phi, nf))
     return poses.to(device) if device is not None else poses
 
 
-# ---------------------------------------------------------------------------------------------------
-# LLFF (forward-facing) camera path: dataset/load_llff.py:151-204 and the spiral set-up of :277-346.
-# Poses are [N, 3, 5] camera-to-world matrices with the (H, W, focal) column of poses_bounds.npy appended.
-# ---------------------------------------------------------------------------------------------------
-def normalize(x):
-    """load_llff.py:151-152."""
-    return x / np.linalg.norm(x)
+# LLFF (forward-facing) rigs: poses are [N, 3, 5] camera-to-world matrices with the (H, W, focal) column of poses_bounds.npy appended
+# (dataset/load_llff.py:151-204; the spiral set-up of :277-346).  Arithmetic stays in the dtype the loader has at that point (the rig is
+# fp32 once loaded, the spiral is float64): the fixtures pin these paths bit for bit.  The last axis is the vector axis.
+def _unit(v: np.ndarray) -> np.ndarray:
+    """Vectors scaled to unit length along the last axis (one vector: numpy's own 2-norm, so an fp32 vector rounds as it does in the loader)."""
+    if v.ndim == 1:
+        return v / np.linalg.norm(v)
+    return v / np.sqrt(np.square(v).sum(-1, keepdims=True))
 
 
-def viewmatrix(z, up, pos):
-    """Camera frame looking along ``z`` with ``up`` as the approximate y axis (load_llff.py:155-161) -> [3, 4]."""
-    back = normalize(z)
-    right = normalize(np.cross(up, back))
-    true_up = normalize(np.cross(back, right))
-    return np.stack([right, true_up, back, pos], 1)
+def look_frames(back: np.ndarray, up: np.ndarray, eye: np.ndarray) -> np.ndarray:
+    """Camera frames [..., 3, 4] = (right, up', back, eye) as columns for cameras at ``eye`` whose z axis is ``back`` and whose y axis is as
+    close to ``up`` as orthogonality allows (load_llff.py:155-161, for any number of cameras at once; ``up`` broadcasts)."""
+    z = _unit(np.asarray(back))
+    x = _unit(np.cross(np.broadcast_to(up, z.shape), z))
+    y = _unit(np.cross(z, x))
+    return np.stack([x, y, z, np.broadcast_to(eye, z.shape)], -1)
 
 
-def poses_avg(poses):
-    """Average camera of a rig (load_llff.py:169-176) -> [3, 5]: mean position, summed viewing / up directions, hwf of pose 0."""
-    hwf = poses[0, :3, -1:]
-    center = poses[:, :3, 3].mean(0)
-    back = normalize(poses[:, :3, 2].sum(0))
-    up = poses[:, :3, 1].sum(0)
-    return np.concatenate([viewmatrix(back, up, center), hwf], 1)
+def rig_average(poses: np.ndarray) -> np.ndarray:
+    """The average camera of a rig [3, 5] (load_llff.py:169-176): mean position, summed viewing and up directions, hwf of camera 0."""
+    # the summed viewing direction is made a unit vector BEFORE the frame is built (which scales it again): in fp32 the second pass can
+    # move an ulp, and the loader does both
+    frame = look_frames(_unit(poses[:, :3, 2].sum(0)), poses[:, :3, 1].sum(0), poses[:, :3, 3].mean(0))
+    return np.concatenate([frame, poses[0, :3, -1:]], 1)
 
 
-def render_path_spiral(c2w, up, rads, focal, zdelta, zrate, rots, N):
-    """``N`` poses on a spiral around ``c2w`` looking at the point ``focal`` in front of it (load_llff.py:179-189).
-    ``zdelta`` is accepted and unused, as in the reference."""
-    rads = np.array(list(rads) + [1.])
-    hwf = c2w[:, 4:5]
-    out = []
-    for theta in np.linspace(0., 2. * np.pi * rots, int(N) + 1)[:-1]:
-        eye = np.dot(c2w[:3, :4], np.array([np.cos(theta), -np.sin(theta), -np.sin(theta * zrate), 1.]) * rads)
-        look = normalize(eye - np.dot(c2w[:3, :4], np.array([0, 0, -focal, 1.])))
-        out.append(np.concatenate([viewmatrix(look, up, eye), hwf], 1))
-    return out
+def spiral_path(c2w: np.ndarray, up: np.ndarray, radii, focus: float, zrate: float, rots: float, n: int) -> np.ndarray:
+    """``n`` cameras [n, 3, 5] on a spiral around the camera ``c2w`` [3, 5], all looking at the point ``focus`` in front of it
+    (load_llff.py:179-189).  In c2w's own frame camera k sits at radii * (cos t, -sin t, -sin(zrate t)), t = 2 pi rots k / n."""
+    t = np.linspace(0.0, 2.0 * np.pi * rots, int(n) + 1)[:-1]
+    frame = c2w[:3, :4]
+    local = np.stack([np.cos(t), -np.sin(t), -np.sin(t * zrate), np.ones_like(t)], -1) * np.append(np.asarray(radii, dtype=np.float64), 1.0)
+    eyes = (local[:, None, :] * frame[None]).sum(-1)                  # frame @ local_k for every k
+    target = (frame * np.array([0.0, 0.0, -focus, 1.0])).sum(-1)
+    cams = look_frames(eyes - target, up, eyes)
+    return np.concatenate([cams, np.broadcast_to(c2w[:, 4:5], (len(t), 3, 1))], -1)
 
 
-def recenter_poses(poses):
-    """Express every pose in the frame of the average camera (load_llff.py:192-204)."""
+def recenter_rig(poses: np.ndarray) -> np.ndarray:
+    """Every camera of the rig expressed in the frame of the rig's average camera (load_llff.py:192-204)."""
+    last_row = np.array([0.0, 0.0, 0.0, 1.0])
+    world_from_avg = np.vstack([rig_average(poses)[:3, :4], last_row])
+    homog = np.concatenate([poses[:, :3, :4], np.broadcast_to(last_row, (poses.shape[0], 1, 4))], 1)
     out = poses + 0
-    bottom = np.reshape([0, 0, 0, 1.], [1, 4])
-    c2w = np.concatenate([poses_avg(poses)[:3, :4], bottom], -2)
-    rows = np.tile(np.reshape(bottom, [1, 1, 4]), [poses.shape[0], 1, 1])
-    p44 = np.concatenate([poses[:, :3, :4], rows], -2)
-    p44 = np.linalg.inv(c2w) @ p44
-    out[:, :3, :4] = p44[:, :3, :4]
+    out[:, :3, :4] = (np.linalg.inv(world_from_avg) @ homog)[:, :3, :4]
     return out
 
 
 def llff_render_poses(poses, bds, path_zflat: bool = False, n_views: int = 120, n_rots: int = 2) -> np.ndarray:
-    """The spiral the loader derives from the recentred rig and its depth bounds (load_llff.py:294-328) -> fp32 [n, 3, 5].
-    ``path_zflat``: the reference halves ``N_views`` with a true division and then fails inside np.linspace on current numpy
-    (load_llff.py:321,184); here the count stays an integer."""
-    c2w = poses_avg(poses)
-    up = normalize(poses[:, :3, 1].sum(0))
-    close_depth, inf_depth = bds.min() * .9, bds.max() * 5.           # a "focus depth" between the bounds, in disparity
-    dt = .75
-    focal = 1. / (((1. - dt) / close_depth + dt / inf_depth))
-    zdelta = close_depth * .2
-    rads = np.percentile(np.abs(poses[:, :3, 3]), 90, 0)
+    """The spiral the loader derives from the recentred rig and its depth bounds (load_llff.py:294-328) -> fp32 [n, 3, 5]: centred on the
+    rig's average camera, focused at a depth 3/4 of the way (in disparity) from 0.9 x the nearest to 5 x the farthest bound, with the
+    90th percentile of the cameras' |offsets| as radii.  ``path_zflat``: a flat one-turn path slightly behind the rig; the reference
+    halves ``N_views`` with a true division and then fails inside np.linspace on current numpy (load_llff.py:321,184); here the count
+    stays an integer."""
+    centre = rig_average(poses)
+    up = _unit(poses[:, :3, 1].sum(0))
+    nearest, farthest = bds.min() * .9, bds.max() * 5.
+    focus = 1. / (.25 / nearest + .75 / farthest)
+    radii = np.percentile(np.abs(poses[:, :3, 3]), 90, 0)
     if path_zflat:
-        zloc = -close_depth * .1
-        c2w[:3, 3] = c2w[:3, 3] + zloc * c2w[:3, 2]
-        rads[2] = 0.
-        n_rots = 1
-        n_views //= 2
-    return np.array(render_path_spiral(c2w, up, rads, focal, zdelta, zrate=.5, rots=n_rots, N=n_views)).astype(np.float32)
+        centre[:3, 3] = centre[:3, 3] - nearest * .1 * centre[:3, 2]
+        radii[2] = 0.
+        n_rots, n_views = 1, n_views // 2
+    return spiral_path(centre, up, radii, focus, zrate=.5, rots=n_rots, n=n_views).astype(np.float32)
 
 
 def llff_cameras(raw_poses, raw_bds, bd_factor=.75, path_zflat: bool = False) -> Dict:
     """Everything load_llff() derives from ``poses_bounds.npy`` (raw_poses [3,5,N], raw_bds [2,N]; load_llff.py:277-346) except
     the images: axis reorder, rescale by the near bound, recentring, the render spiral, intrinsics.  Returns a dict with
     ``poses`` [N,3,5], ``bds`` [N,2], ``render_poses`` [120,3,5], ``gt_extrinsic`` [N,3,4], ``gt_intrinsic`` [3,3], ``hw``."""
-    poses = np.concatenate([raw_poses[:, 1:2, :], -raw_poses[:, 0:1, :], raw_poses[:, 2:, :]], 1)
-    poses = np.moveaxis(poses, -1, 0).astype(np.float32)
+    # (x, y, z) columns of poses_bounds are (down, right, back): reorder to (right, up, back); cameras first
+    poses = np.moveaxis(np.concatenate([raw_poses[:, 1:2, :], -raw_poses[:, 0:1, :], raw_poses[:, 2:, :]], 1), -1, 0).astype(np.float32)
     bds = np.moveaxis(raw_bds, -1, 0).astype(np.float32)
-    sc = 1. if bd_factor is None else 1. / (bds.min() * bd_factor)
-    poses[:, :3, 3] *= sc
-    bds *= sc
-    poses = recenter_poses(poses)
+    scale = 1. if bd_factor is None else 1. / (bds.min() * bd_factor)
+    poses[:, :3, 3] *= scale
+    bds *= scale
+    poses = recenter_rig(poses)
     render_poses = llff_render_poses(poses, bds, path_zflat)
     poses = poses.astype(np.float32)
     H, W, focal = poses[0, :3, -1]

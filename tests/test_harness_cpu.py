@@ -14,7 +14,12 @@ from nerf_pytorch_paeng_amd.model import NeRF
 
 
 def test_render_pose_matches_reference(golden):
+    """All poses of a spherical path come from ONE closed-form array expression (harness.spherical_poses): bit for bit the reference's
+    per-pose matrix chain (fixture F10), for a whole circle, a single view, and any subset of azimuths at once."""
     g = golden("F10_callers")
+    np.testing.assert_array_equal(harness.spherical_poses(np.linspace(-180, 180, 9)[:-1], -30.0, 4.0), g["poses8"])
+    np.testing.assert_array_equal(harness.spherical_poses([33.0, 120.0], -41.0, 4.0)[0], g["pose_sph"])
+    assert harness.spherical_poses(np.linspace(-180, 180, 41)[:-1], -30.0, 4.0).shape == (40, 4, 4)
     np.testing.assert_array_equal(harness.get_render_pose(n_angle=8, single_angle=-1, phi=-30.0, nf=4.0).numpy(), g["poses8"])
     np.testing.assert_array_equal(harness.get_render_pose(n_angle=1, single_angle=120, phi=-20.0, nf=3.5).numpy(), g["pose_single"])
     np.testing.assert_array_equal(harness.pose_spherical(33.0, -41.0, 4.0).numpy(), g["pose_sph"])
@@ -104,13 +109,22 @@ def test_F12_llff_spiral_path(golden):
     # building blocks.  The loader's arrays keep the memory order of poses_bounds ([3,5,N] moved to [N,3,5] as a view), and
     # numpy's reductions over axis 0 round differently for different strides: rebuild that layout for the bit-exact check
     rec = np.moveaxis(np.ascontiguousarray(np.moveaxis(g["rec_poses"], 0, -1)), -1, 0)
-    np.testing.assert_array_equal(Hn.poses_avg(rec), g["poses_avg"])
-    np.testing.assert_allclose(Hn.poses_avg(g["rec_poses"]), g["poses_avg"], atol=1e-7)
-    np.testing.assert_array_equal(Hn.normalize(g["normalize_in"]), g["normalize_out"])
-    np.testing.assert_array_equal(Hn.viewmatrix(rec[0, :3, 2], rec[1, :3, 1], rec[2, :3, 3]), g["viewmatrix_out"])
-    sp = np.array(Hn.render_path_spiral(g["poses_avg"], Hn.normalize(rec[:, :3, 1].sum(0)), np.array([0.3, 0.2, 0.1]), 3.5, 0.2, zrate=.5, rots=2, N=9))
-    np.testing.assert_array_equal(sp, g["spiral_direct"])
-    np.testing.assert_array_equal(Hn.recenter_poses(rec), Hn.recenter_poses(rec))
+    np.testing.assert_array_equal(Hn.rig_average(rec), g["poses_avg"])
+    np.testing.assert_allclose(Hn.rig_average(g["rec_poses"]), g["poses_avg"], atol=1e-7)
+    np.testing.assert_array_equal(Hn._unit(g["normalize_in"]), g["normalize_out"])
+    np.testing.assert_array_equal(Hn.look_frames(rec[0, :3, 2], rec[1, :3, 1], rec[2, :3, 3]), g["viewmatrix_out"])
+    # all nine cameras of a spiral from ONE array expression: float64, the reference's per-camera loop agrees to the last-but-one bit
+    # (sums of four products in another association) and exactly once rounded to the fp32 the loader hands out
+    sp = Hn.spiral_path(g["poses_avg"], Hn._unit(rec[:, :3, 1].sum(0)), np.array([0.3, 0.2, 0.1]), 3.5, zrate=.5, rots=2, n=9)
+    assert sp.shape == (9, 3, 5) and sp.dtype == np.float64
+    np.testing.assert_allclose(sp, g["spiral_direct"], rtol=0, atol=5e-16)
+    np.testing.assert_array_equal(sp.astype(np.float32), g["spiral_direct"].astype(np.float32))
+    # a batch of frames equals the frames one by one
+    many = Hn.look_frames(rec[:, :3, 2].astype(np.float64), rec[1, :3, 1].astype(np.float64), rec[:, :3, 3].astype(np.float64))
+    for i in range(rec.shape[0]):
+        np.testing.assert_allclose(many[i], Hn.look_frames(rec[i, :3, 2].astype(np.float64), rec[1, :3, 1].astype(np.float64), rec[i, :3, 3].astype(np.float64)),
+                                   rtol=0, atol=5e-16)
+    np.testing.assert_array_equal(Hn.recenter_rig(rec), Hn.recenter_rig(rec))
     # properties: every spiral camera is orthonormal and looks at the focus point; the flat path halves the view count
     Rm = cam["render_poses"][:, :3, :3].astype(np.float64)
     np.testing.assert_allclose(np.einsum("nij,nik->njk", Rm, Rm), np.broadcast_to(np.eye(3), (120, 3, 3)), atol=1e-6)
