@@ -43,12 +43,13 @@ F16_MAX = 65504.0
 class _TrainState:
     """Per-model constants of the training path: network shape and the device-side pack maps."""
 
-    def __init__(self, model: torch.nn.Module, device: torch.device):
+    def __init__(self, model: torch.nn.Module, device: torch.device, f16s: bool = False):
         sd = model.state_dict()
         # net_model: the module's own shape (model/NeRF.py:24-30); net: what the training kernels run -- the same, or for a width without
         # training kernels (--netWidth 64, config.py:57) the next wider one, parameters scattered into zeros (weights.pad_index_map)
         self.net_model: Net = infer_net(sd)
-        self.net: Net = padded_train_net(self.net_model)
+        # ... which depends on the precision: the split-precision kernels exist for W = 256 only (one state per kernel width, _state_for)
+        self.net: Net = padded_train_net(self.net_model, f16s)
         self.pad_idx = None if self.net is self.net_model else pad_index_map(self.net_model, self.net).to(device)
         self.n_flat = ops.param_count(self.net)
         self.device = device
@@ -145,17 +146,24 @@ class _TrainState:
             raise MiNerfError(f"module lacks parameter {e} (expected the layout of model/NeRF.py:24-30)") from e
 
 
-_states: "weakref.WeakKeyDictionary[torch.nn.Module, _TrainState]" = weakref.WeakKeyDictionary()
+# model -> {kernel width: state}: a netWidth below 128 trains 128 wide in fp32 and 256 wide in split precision
+_states: "weakref.WeakKeyDictionary[torch.nn.Module, Dict[int, _TrainState]]" = weakref.WeakKeyDictionary()
 
 
-def _state_for(model: torch.nn.Module) -> _TrainState:
+def _state_for(model: torch.nn.Module, f16s: bool = False) -> _TrainState:
     dev = next(model.parameters()).device
     if dev.type != "cuda":
         raise MiNerfError(f"model lives on {dev}: the MI355X path needs a HIP device (no CPU fallback)")
-    st = _states.get(model)
-    if st is None or st.device != dev:
-        st = _TrainState(model, dev)
-        _states[model] = st
+    per_width = _states.get(model)
+    if per_width is None:
+        per_width = _states[model] = {}
+    known = next(iter(per_width.values()), None)
+    if known is not None:                                  # the module's own shape is on record: which kernel width does this precision train at?
+        st = per_width.get(padded_train_net(known.net_model, f16s).W)
+        if st is not None and st.device == dev:
+            return st
+    st = _TrainState(model, dev, f16s)
+    per_width[st.net.W] = st
     return st
 
 
@@ -258,9 +266,7 @@ def render_train(rays: torch.Tensor, model: torch.nn.Module, opts, *, t_rand=Non
                  z_override=None, det: Optional[bool] = None, f16s: bool = False) -> Dict[str, torch.Tensor]:
     """Differentiable ``render_rays`` (nerf_process.py:185-216) for one slab of rays [n, 6].  ``f16s``: the two forward launches run in
     split precision (fp32-grade results, ~3x faster); the backward kernels are the fp32 ones."""
-    st = _state_for(model)
-    if f16s and st.net.W != 256:
-        raise MiNerfError(f"the split-precision forward is built for netWidth 256 (got {st.net.W})")
+    st = _state_for(model, f16s)                 # f16s: the 256-wide state (any netWidth <= 256 is scattered into it)
     dev = st.device
     if isinstance(rays, torch.Tensor) and rays.requires_grad:
         raise MiNerfError("rays require grad: the training path differentiates w.r.t. the MLP parameters only (the reference trains "
@@ -290,7 +296,7 @@ def f16s_status(model: torch.nn.Module, reset: bool = True) -> Dict[str, float]:
     (how much of the f16 range the scaled backward chain used; >= 65504 means a conversion saturated and gradients were clipped), the number
     of weights the split-precision packers could not represent, and ``saturated``.  The training path itself reads these after each of the first
     F16S_CHECK_FIRST f16s steps and every F16S_CHECK_EVERY-th after them, and raises / warns; this is the on-demand read."""
-    st = _states.get(model)
+    st = next((s for s in (_states.get(model) or {}).values() if s.f16s_range is not None), None)
     if st is None:
         return {"max_abs_d_raw": 0.0, "max_abs_delta_scaled": 0.0, "weights_out_of_range": 0, "saturated": False}
     return st.read_f16s(reset)

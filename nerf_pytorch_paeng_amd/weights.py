@@ -8,6 +8,7 @@ shapes, packs both networks into the kernels' streaming layout and keeps the blo
 """
 from __future__ import annotations
 
+import weakref
 from typing import Dict, Optional, Tuple
 
 import numpy as np
@@ -55,14 +56,15 @@ def _param_shape(net: Net, key: str) -> Tuple[int, ...]:
     return (out, fan_in) if kind == "weight" else (out,)
 
 
-def padded_train_net(net: Net) -> Net:
-    """The network the TRAINING kernels run for ``net``: they exist for W = 128 and 256, a narrower network trains as the next of the two with
-    zero weights and biases for the hidden units it does not have (``pad_index_map``)."""
-    if net.W in (128, 256):
+def padded_train_net(net: Net, f16s: bool = False) -> Net:
+    """The network the TRAINING kernels run for ``net``: the fp32 kernels exist for W = 128 and 256, the split-precision ones (``f16s``) for
+    W = 256 only; a narrower network trains as the next width that has kernels -- so the width depends on the precision: netWidth 64 trains
+    128 wide in fp32 and 256 wide in split precision -- with zero weights and biases for the hidden units it does not have (``pad_index_map``)."""
+    if net.W == 256 or (net.W == 128 and not f16s):
         return net
     if not 2 <= net.W < 256:
         raise MiNerfError(f"the training kernels exist for netWidth <= 256 (got {net.W}); wider networks run inference only")
-    return ops.make_net(net.D, 128 if net.W < 128 else 256, net.skip, net.L_x, net.L_d)
+    return ops.make_net(net.D, 256 if (f16s or net.W > 128) else 128, net.skip, net.L_x, net.L_d)
 
 
 def padded_256_net(net: Net, what: str) -> Net:
@@ -130,6 +132,7 @@ class PackedNeRF:
         self._sd = None
         self._flat: Optional[Tuple[torch.Tensor, torch.Tensor]] = None      # device-resident flat parameter vectors (nn.Module source)
         self.f16s_out_of_range: Optional[torch.Tensor] = None               # device int32 [1], set by the device-side f16s packer
+        self._range_token = None     # (module, parameter-version key) when packed from an nn.Module: lets f16s() reuse a range verdict (_f16s_verdicts)
 
     @property
     def device(self) -> torch.device:
@@ -197,9 +200,9 @@ class PackedNeRF:
         vectors when this PackedNeRF came from an nn.Module (like bf16(): packed_for() makes a new one per call, so a host round trip
         here would be a synchronisation per render call), on the host from the kept state dict otherwise (once; the host packer refuses
         weights beyond the f16 range outright).  The device packer cannot refuse: it counts such weights into ``f16s_out_of_range``
-        (a device int32), which ``check_f16s_range()`` reads -- here, once, right after the pack launches (a 4-byte device -> host read
-        per packing, i.e. per no-grad render call on an nn.Module; a frozen PackedNeRF pays it once): EVERY caller of the split-precision
-        mode gets the refusal the host packer gives, not a NaN frame."""
+        (a device int32), which ``check_f16s_range()`` reads -- here, right after the pack launches, ONCE PER VERSION of the module's
+        parameters (a 4-byte device -> host read; later render calls on unchanged parameters reuse the verdict and do not synchronise;
+        a frozen PackedNeRF pays it once): every caller of the split-precision mode gets the refusal the host packer gives."""
         if self._f16s is None:
             wide = self.kernel_net(f16s=True)
             if self._flat is not None:
@@ -208,7 +211,14 @@ class PackedNeRF:
                     _maps_f16s[key] = ops.pack_map_f16s(wide).to(self.device)
                 self.f16s_out_of_range = torch.zeros(1, dtype=torch.int32, device=self.device)
                 blobs = tuple(ops.pack_apply_f16s(wide, _maps_f16s[key], flat, self.f16s_out_of_range) for flat in self._wide_flats(wide))
-                self.check_f16s_range()
+                # the 4-byte read synchronises the host: pay it once per parameter VERSION of the module, not once per render call
+                # (packed_for() makes a new PackedNeRF per call).  A write through p.data does not bump the version; a weight pushed
+                # out of range that way still cannot give a finite wrong colour -- it packs to NaN and the frame is NaN.
+                module, version_key = self._range_token if self._range_token is not None else (None, None)
+                if module is None or _f16s_verdicts.get(module) != version_key:
+                    self.check_f16s_range()
+                    if module is not None:
+                        _f16s_verdicts[module] = version_key
                 self._f16s = blobs
             else:
                 if self._sd is None:
@@ -253,6 +263,8 @@ def packed_for(model, device=None) -> PackedNeRF:
     return _pack_module_on_device(model, torch.device(device))
 
 
+# module -> the parameter-version key ((data_ptr, _version) of every parameter) whose split-precision range check came back clean
+_f16s_verdicts: "weakref.WeakKeyDictionary[torch.nn.Module, tuple]" = weakref.WeakKeyDictionary()
 # gather maps per network shape (built once by the host packer, kept on the device)
 _maps: Dict[tuple, torch.Tensor] = {}
 _maps_bf16: Dict[tuple, torch.Tensor] = {}
@@ -274,4 +286,5 @@ def _pack_module_on_device(model: torch.nn.Module, device: torch.device) -> Pack
     blobs = [ops.pack_apply(_maps[key], flat) for flat in flats]
     packed = PackedNeRF(net, blobs[0], blobs[1])
     packed._flat = (flats[0], flats[1])      # the bf16 variant is packed from these, lazily, on the device
+    packed._range_token = (model, tuple((p.data_ptr(), p._version) for p in model.parameters()))
     return packed

@@ -138,6 +138,22 @@ def test_module_source_f16s_blobs_are_packed_on_the_device(lego_rays):
     want = weights.PackedNeRF.from_state_dict(sd, DEV).f16s()
     assert all(torch.equal(a, b) for a, b in zip(got, want))
     assert dev_blobs.check_f16s_range() == 0
+    # the range read synchronises the host: it is paid once per VERSION of the parameters, not once per render call
+    reads = []
+    orig = weights.PackedNeRF.check_f16s_range
+    weights.PackedNeRF.check_f16s_range = lambda self: (reads.append(1), orig(self))[1]
+    try:
+        with torch.no_grad():
+            for _ in range(3):
+                NP.render_rays(lego_rays[:64].contiguous(), model, None, make_opts(), seed=1, f16s=True)
+        assert reads == []                                           # verdict of this parameter version already on record (f16s() above)
+        with torch.no_grad():
+            model.model_fine.linear_x[2].bias[0] += 0.5              # an in-place update = a new version: checked again, once
+            for _ in range(2):
+                NP.render_rays(lego_rays[:64].contiguous(), model, None, make_opts(), seed=1, f16s=True)
+        assert reads == [1]
+    finally:
+        weights.PackedNeRF.check_f16s_range = orig
     with torch.no_grad():
         model.model_fine.linear_x[2].weight[3, 5] = 1.0e6
     bad = packed_for(model)
@@ -555,4 +571,5 @@ def test_f16s_training_llff_and_two_slabs(monkeypatch):
     for k, a in res[False][2].items():
         b = res[True][2][k]
         assert torch.isfinite(b).all() and float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()) + 1e-12, k
-    assert harness._precision(make_opts(precision="f16s")) == {"bf16": False, "f16s": True}
+    assert harness._precision(make_opts(precision="f16s")) == {"bf16": False, "f16s": True, "coarse_f16s": False}
+    assert harness._precision(make_opts(precision="f16s+bf16")) == {"bf16": True, "f16s": False, "coarse_f16s": True}

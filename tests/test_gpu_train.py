@@ -216,7 +216,7 @@ def _train_setup(D=8, W=256, n=96, Sc=32, Nf=48, seed=0):
     return sd, model, posenc, opts, o, d, t_rand, u, target, cfg
 
 
-@pytest.mark.parametrize("D,W,f16s", [(8, 256, False), (8, 256, True), (8, 64, False), (6, 100, False), (8, 200, False), (8, 200, True)])
+@pytest.mark.parametrize("D,W,f16s", [(8, 256, False), (8, 256, True), (8, 64, False), (6, 100, False), (8, 200, False), (8, 200, True), (8, 64, True)])
 def test_train_step_gradients_match_oracle_autograd(D, W, f16s):
     """``f16s``: the same step with its three MFMA kernels in split precision, same bars.  Widths without training kernels of their own
     (--netWidth 64 / 100 / 200, config.py:57) train as the next wider network, the parameters scattered into zeros and the gradient gathered
@@ -253,6 +253,13 @@ def test_train_step_gradients_match_oracle_autograd(D, W, f16s):
         opt.step()
         out2 = train_path.render_train(rays, model, opts, t_rand=t_rand, u=u, z_override=(z_c.to(DEV), z_f), f16s=f16s)
         assert torch.isfinite(out2["rgb_f"]).all() and not torch.equal(out2["rgb_f"], out["rgb_f"])
+    if W == 64 and f16s:
+        # the training width depends on the precision: netWidth 64 trains 256 wide in split precision (the only width those kernels have)
+        # and 128 wide in fp32 -- one state per kernel width for the same module, either order
+        out3 = train_path.render_train(rays, model, opts, t_rand=t_rand, u=u, z_override=(z_c.to(DEV), z_f), f16s=False)
+        assert torch.isfinite(out3["rgb_f"]).all() and float((out3["rgb_f"] - out2["rgb_f"]).abs().max()) < 1e-4
+        assert sorted(train_path._states[model]) == [128, 256]
+        assert train_path.f16s_status(model, reset=False)["weights_out_of_range"] == 0
 
 
 def test_drop_in_training_loop_runs_and_repacks():
