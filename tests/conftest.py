@@ -44,3 +44,10 @@ def fake_rccl_lib(tmp_path_factory):
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     return lib
+
+
+@pytest.fixture(scope="session")
+def oracle_cache():
+    """Results of the CPU oracle that more than one GPU test needs for the same inputs (BASELINE config #2, all 4096 rays, ~6 s of CPU per
+    evaluation): computed by whoever asks first, keyed by the caller."""
+    return {}

@@ -172,7 +172,7 @@ def test_module_source_f16s_blobs_are_packed_on_the_device(lego_rays):
         harness.test(0, [0], posenc, model, torch.zeros(1, 8, 8, 3), K, pose[None], (8, 8), opts)
 
 
-def test_f16s_config2_all_rays_vs_oracle(packed_big, lego_rays):
+def test_f16s_config2_all_rays_vs_oracle(packed_big, lego_rays, oracle_cache):
     """BASELINE config #2 at full size through the split-precision variant, EVERY ray against the CPU oracle, to the bars the fp32
     path is held to (test_config2_all_rays_vs_oracle): coarse colours and disparities directly; fine outputs with the depths pinned to
     the ones the HIP path sampled; un-pinned rays more than 1e-4 off: at most 1 %."""
@@ -183,7 +183,10 @@ def test_f16s_config2_all_rays_vs_oracle(packed_big, lego_rays):
     torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
     rc, tr, uu = lego_rays.cpu(), a["_t_rand"].cpu(), a["_u"].cpu()
     with torch.no_grad():
-        ref = R.render_rays(rc, sd, R.PathConfig(), tr, uu)
+        if "config2_seed11" not in oracle_cache:             # shared with tests/test_gpu_parity.py::test_config2_all_rays_vs_oracle (same rays, same jitter)
+            oracle_cache["config2_seed11"] = (tr, uu, R.render_rays(rc, sd, R.PathConfig(), tr, uu))
+        tr0, uu0, ref = oracle_cache["config2_seed11"]
+        assert torch.equal(tr0, tr) and torch.equal(uu0, uu)
         pin = R.render_rays(rc, sd, R.PathConfig(), tr, uu, z_fine_override=a["_z_f"].cpu())
     e_c = float((a["rgb_c"].cpu() - ref["rgb_c"]).abs().max())
     e_dc = float((a["disp_c"].cpu() - ref["disp_c"]).abs().max())
