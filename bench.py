@@ -862,7 +862,8 @@ def worker(args) -> None:
         n_rays_gb = n_img * H * W
         b_gen = n_rays_gb * (12 + 36)                     # read the pixel, write (o, d, rgb)
         b_perm = n_rays_gb * (36 + 36 + 8)                # gather + write + the permutation itself
-        # a random 36-byte row is one 128-byte HBM request, two when it straddles a line (offsets 96..124 of 128: 8 of 32 four-byte positions)
+        # a random 36-byte row is one 128-byte HBM request, two when it straddles a line (offsets 96..124 of 128: 8 of 32 four-byte positions): MEASURED,
+        # TCC_EA0_RDREQ = 1.25 per row exactly (profiles/r06_staging_pmc_req.json, r06_permute_rows_bound.txt); the permutation streams (8 B per row)
         b_perm_hbm = n_rays_gb * (128 * 1.25 + 36 + 8)
         staging = {"what": f"main.py:92-102 on the device: rays_rgb for {n_img} {H}x{W} images ({n_rays_gb * 36 / 1e9:.2f} GB); the epoch shuffle is a permutation "
                            f"held beside the table (harness.ShuffledRows), a step gathers its {N_RAYS} rows through it (train.py:29)",
@@ -871,10 +872,12 @@ def worker(args) -> None:
                    "batch_gather_is": "ops.gather_rows (mi_nerf_permute_rows, n = B) of one step's rows from the unshuffled table, hipEvents on the launch stream, "
                                       "median of 45; launch-bound (147 KB moved); per epoch: 15 625 steps x this instead of one shuffle_ms and a second 2.3 GB table",
                    "materialized_shuffle": {"ms": round(e1.elapsed_time(e2), 3), "GBps_algorithmic": round(b_perm / e1.elapsed_time(e2) / 1e6, 1),
-                                            "GBps_hbm_requests_estimated": round(b_perm_hbm / e1.elapsed_time(e2) / 1e6, 1),
-                                            "why_not_used": "a random 36-byte row costs a 128-byte HBM request (1.25 on average): 80 algorithmic bytes per row move "
-                                                            "~204, so 8 TB/s of HBM caps the algorithmic rate near 3.1 TB/s whatever the kernel; "
-                                                            "the training loop no longer materialises the shuffle (profiles/r06_permute_rows_bound.txt)"},
+                                            "GBps_hbm_traffic": round(b_perm_hbm / e1.elapsed_time(e2) / 1e6, 1),
+                                            "hbm_traffic_is": "this run's time x the bytes the PMC passes counted for this kernel and table (1.25 128-byte read requests per "
+                                                              "36-byte row, every written byte once: profiles/r06_staging_pmc_req.json, r06_staging_pmc_write.json)",
+                                            "why_not_used": "a random 36-byte row costs a 128-byte HBM request (1.25 measured): 80 algorithmic bytes per row move 204, the "
+                                                            "kernel runs at the HBM rate in the bytes it really moves, and 8 TB/s caps the algorithmic rate at 3.1 TB/s "
+                                                            "whatever the kernel; the training loop no longer materialises the shuffle (profiles/r06_permute_rows_bound.txt)"},
                    "hbm_peak_GBps": 8000}
         del imgs, rr, rr2, shuffled, batch
         torch.cuda.empty_cache()
