@@ -14,7 +14,9 @@ REQUIRED = {"metric": str, "value": (int, float), "unit": str, "n_gpus": int, "s
                                   "r03_bench_n1.json", "r03_bench_n1_bf16.json", "r03_bench_n1_fern.json", "r03_bench_n4_gloo_rehearsal.json",
                                   "r03_bench_rank3_of_8_alone.json", "r03_bench_n1_with_f16_split.json", "r04_bench_n1.json", "r04_bench_n4_gloo_rehearsal.json",
                                   "r05_bench_n1.json", "r05_driver_command_bench_line.json", "r05_bench_n4_gloo_rehearsal.json",
-                                  "r05_bench_one_rank_rccl_collective.json", "r05_bench_n1_fern.json", "r05_bench_n1_bf16.json"])
+                                  "r05_bench_one_rank_rccl_collective.json", "r05_bench_n1_fern.json", "r05_bench_n1_bf16.json",
+                                  "r06_driver_command_bench_line.json", "r06_bench_n4_both_routes_lego.json", "r06_bench_n4_both_routes_fern.json",
+                                  "r06_bench_one_rank_rccl_both_routes.json"])
 def test_committed_bench_line_has_the_contract_fields(name):
     path = os.path.join(ROOT, "profiles", name)
     with open(path) as f:
@@ -55,6 +57,28 @@ def test_committed_bench_line_has_the_contract_fields(name):
             assert line["frame_checksum"] == line["collective"]["frame_checksum_rank0"]
     if name.startswith("r04") and line["n_gpus"] == 1:
         assert "collective" not in line                   # the N = 1 line is unchanged
+    if name.startswith("r06"):
+        with open(os.path.join(ROOT, "BASELINE.json"), encoding="utf-8") as f:
+            assert line["metric"] == json.load(f)["metric"]                     # byte for byte (U+00D7), read from the file
+        if "collective" in line:
+            # round 6: ONE run times the frame through both gather routes and the checksums agree; lego's is the N = 1 line's number
+            c = line["collective"]
+            assert c["tile_gather_route"] == "torch" and "error" not in c["c_abi"]
+            assert c["c_abi"]["equal_to_torch_route_on_every_rank"] is True and c["c_abi"]["frame_checksum_equals_torch_route_on_every_rank"] is True
+            assert line["frame_ms"] > 0 and line["frame_ms_c_abi"] > 0 and line["frame_checksum_c_abi"] == line["frame_checksum"] == c["frame_checksum_rank0"]
+            assert c["world_size"] == line["n_gpus"] and c["c_abi"]["world_size"] == line["n_gpus"]
+            if "fern" not in name:
+                assert line["frame_checksum"] == 3074984520147328127
+            else:
+                assert c["c_abi"]["staging_bytes"] > 0                           # 378 rows over 4 ranks: the ragged path
+        else:
+            assert "frame_ms_c_abi" not in line and line["frame_checksum"] == 3074984520147328127
+            st = line["staging"]
+            assert st["batch_gather_rows"] == 4096 and 0 < st["batch_gather_us"] < 200 and st["materialized_shuffle"]["GBps_algorithmic"] > 1500
+            b = line["bf16"]
+            assert b["peaked"]["coarse_f16s_fine_bf16"]["psnr_rgb_f_vs_fp32_dB"] > b["peaked"]["bf16"]["psnr_rgb_f_vs_fp32_dB"]
+            assert b["coarse_f16s_fine_bf16"]["psnr_rgb_c_vs_fp32_dB"] > 100 and "sample positions" in b["what"].lower()
+            assert line["roofline"]["traffic_is_current"] is True
     if name in ("r05_bench_n4_gloo_rehearsal.json", "r05_bench_one_rank_rccl_collective.json"):
         c = line["collective"]                            # round 5: which route assembled the timed frames, and the C ABI's route beside it where RCCL is the backend
         assert c["tile_gather_route"] == "torch" and c["frame_equal_across_ranks"] is True and c["neighbour_tile_recomputed_equal"] is True
