@@ -258,7 +258,7 @@ def test_bench_line_survives_a_wedged_c_abi_collective(fake_rccl_lib):
     all-gather sleeps for ever on every rank) the ranks give up after BENCH_C_ABI_TIMEOUT_S, issue no further GPU or process-group call, rank 0 still prints
     the ONE line -- with `c_abi: {"error": "hung..."}` and everything the torch route measured -- and the job ends with status 75: a hang is not a success."""
     lib = fake_rccl_lib
-    env = dict(os.environ, BENCH_BACKEND="gloo", MI_NERF_RCCL_LIB=lib, FAKE_RCCL_HANG_AFTER="3", BENCH_C_ABI_TIMEOUT_S="8", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, BENCH_BACKEND="gloo", MI_NERF_RCCL_LIB=lib, FAKE_RCCL_HANG_AFTER="3", BENCH_C_ABI_TIMEOUT_S="5", HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--frames", "1", "--no-cpu-baseline", "--no-bf16-leg",

@@ -151,7 +151,7 @@ def _bench(extra_args, env_extra, timeout=850):
 
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("workload", ["lego", "fern"])
-def test_bench_four_live_ranks_time_both_gather_routes(workload, fake_rccl_lib):
+def test_bench_four_live_ranks_time_both_gather_routes(workload, fake_rccl_lib, packed):
     """`python bench.py --gpus 4`: its own launcher, 4 workers, strong + weak legs, the sharded frame with its all-gather (ragged for
     fern: 95, 95, 94, 94 rows -- through the staging buffer and the un-pad kernel) -- timed through BOTH routes in the one run:
     torch.distributed (frame_ms) and mi_nerf_all_gather_tiles on the library's own communicator (frame_ms_c_abi), equal checksums.
@@ -180,12 +180,18 @@ def test_bench_four_live_ranks_time_both_gather_routes(workload, fake_rccl_lib):
     # of the last timed frame) of this line against a one-GPU run of the same command -- what BENCH (N = 1) and SCALE (N = 8) let a
     # reader check from the driver's records alone
     assert j["frame_checksum"] == c["frame_checksum_rank0"] and isinstance(j["frame_checksum"], int)
+    if workload == "fern":
+        # the same frame rendered by THIS process on one rank (dist.render_frame, the bench's weights / pose / seed), checksummed by bench.py's own function
+        import bench
+        K, H, W, _, opts = _scene("fern")
+        one_rgb, one_disp = mdist.render_frame(H, W, K, synthetic.fern_pose(), packed, opts, seed=0)
+        assert bench.frame_checksum(torch, one_rgb, one_disp) == j["frame_checksum"]
+        return
     one = _bench(["--gpus", "1", "--steps", "3", "--warmup", "1", "--frames", "1", "--no-cpu-baseline", "--train-steps", "0", "--no-small-batch",
                   "--no-bf16-leg", "--no-f16s-leg", "--workload", workload], {})
     assert "collective" not in one and "frame_ms_c_abi" not in one and one["frame_checksum"] == j["frame_checksum"], (one["frame_checksum"], j["frame_checksum"])
-    if workload == "lego":
-        with open(os.path.join(ROOT, "BASELINE.json"), encoding="utf-8") as fh:
-            assert one["metric"] == j["metric"] == json.load(fh)["metric"]
+    with open(os.path.join(ROOT, "BASELINE.json"), encoding="utf-8") as fh:
+        assert one["metric"] == j["metric"] == json.load(fh)["metric"]
 
 
 @pytest.mark.timeout(900)

@@ -37,9 +37,10 @@ from oracle import restate as R
 pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda:0")
 D, WD, SC, NF = 8, 256, 64, 128
-# defaults sized for the GPU suite (~40 s per scene); TRAINED_STEPS / TRAINED_VIEWS / TRAINED_SIZE / TRAINED_SCENES scale the same tests up for a
-# one-off run on longer-trained weights (profiles/r05_trained_weights_long.txt: 20 000 steps, 24 views of 96 x 96)
-N_IMG, N_STEPS, N_RAYS = int(os.environ.get("TRAINED_VIEWS", 8)), int(os.environ.get("TRAINED_STEPS", 4000)), 1024
+# defaults sized for the GPU suite (~22 s per scene: the suite has a 300 s budget); TRAINED_STEPS / TRAINED_VIEWS / TRAINED_SIZE / TRAINED_SCENES scale the
+# same tests up for a one-off run on longer-trained weights (profiles/r05_trained_weights_long.txt: 20 000 steps, 24 views of 96 x 96; rounds 5-6 ran 4000 steps
+# by default: profiles/r05_trained_weights.txt, r06_trained_weights.txt)
+N_IMG, N_STEPS, N_RAYS = int(os.environ.get("TRAINED_VIEWS", 8)), int(os.environ.get("TRAINED_STEPS", 3000)), 1024
 SIZE = int(os.environ.get("TRAINED_SIZE", 48))
 SCENES = tuple(os.environ.get("TRAINED_SCENES", "teacher,solids,teacher_llff,plumbing").split(","))
 
