@@ -95,6 +95,11 @@ def test_tile_gather_helpers_refuse_bad_arguments_before_touching_rccl():
     fake = C.create_string_buffer(64)                                   # not a handle of mi_nerf_comm_init_rank
     assert lib.mi_nerf_all_gather_tiles(fake, None, 1, 8, 8, 4, None, None, 0, None) == EINVAL and b"handle" in lib.mi_nerf_last_error()
     assert lib.mi_nerf_comm_destroy(fake) == EINVAL and lib.mi_nerf_comm_info(fake, None, None, None) == EINVAL
+    # a handle is valid iff it is in the library's registry: an address that is not even mapped (or a handle destroyed earlier, whose memory
+    # is gone) is refused WITHOUT being read -- up to round 5 the check read a magic word through the pointer
+    wild = C.c_void_p(0x10)
+    assert lib.mi_nerf_comm_destroy(wild) == EINVAL and lib.mi_nerf_comm_info(wild, None, None, None) == EINVAL
+    assert lib.mi_nerf_all_gather_tiles(wild, None, 1, 8, 8, 4, None, None, 0, None) == EINVAL and b"handle" in lib.mi_nerf_last_error()
     # staging: nothing for equal blocks; world x largest block for a ragged split (fern: 378 rows over 8 ranks -> 8 x 48 rows)
     assert lib.mi_nerf_all_gather_staging_bytes(8, 800, 800, 4) == 0
     assert lib.mi_nerf_all_gather_staging_bytes(8, 378, 504, 4) == 8 * 48 * 504 * 4 * 4

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Host-side AddressSanitizer + UBSan run of the library's packers, argument checks and layout code (CPU only: GPU ASan is not available on
 # this pool).  Builds build_scratch/libmi_nerf_asan.so with the HOST code instrumented (-fno-gpu-sanitize keeps the device code as shipped)
-# and runs the CPU tests that go through the C ABI against it.  Round 4: 43 tests, no finding; round 5 (padded widths, the W16 packer, the RCCL helpers' argument checks): 148 tests, no finding.
+# and runs the CPU tests that go through the C ABI against it.  Round 4: 43 tests, no finding; round 5 (padded widths, the W16 packer, the RCCL helpers' argument checks): 148 tests, no finding; round 6 (handle registry, staging overlap checks, the row gather's host side): 153 tests, no finding.
 set -e
 cd "$(dirname "$0")/.."
 LIB=$(python - <<'PY'
