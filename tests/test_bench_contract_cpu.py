@@ -15,7 +15,7 @@ REQUIRED = {"metric": str, "value": (int, float), "unit": str, "n_gpus": int, "s
                                   "r03_bench_rank3_of_8_alone.json", "r03_bench_n1_with_f16_split.json", "r04_bench_n1.json", "r04_bench_n4_gloo_rehearsal.json",
                                   "r05_bench_n1.json", "r05_driver_command_bench_line.json", "r05_bench_n4_gloo_rehearsal.json",
                                   "r05_bench_one_rank_rccl_collective.json", "r05_bench_n1_fern.json", "r05_bench_n1_bf16.json",
-                                  "r06_driver_command_bench_line.json", "r06_bench_n4_both_routes_lego.json", "r06_bench_n4_both_routes_fern.json",
+                                  "r06_driver_command_bench_line.json", "r06_bench_n1.json", "r06_bench_n1_bf16.json", "r06_bench_n1_fern.json", "r06_bench_n4_both_routes_lego.json", "r06_bench_n4_both_routes_fern.json",
                                   "r06_bench_one_rank_rccl_both_routes.json"])
 def test_committed_bench_line_has_the_contract_fields(name):
     path = os.path.join(ROOT, "profiles", name)
@@ -71,6 +71,8 @@ def test_committed_bench_line_has_the_contract_fields(name):
                 assert line["frame_checksum"] == 3074984520147328127
             else:
                 assert c["c_abi"]["staging_bytes"] > 0                           # 378 rows over 4 ranks: the ragged path
+        elif name in ("r06_bench_n1_bf16.json", "r06_bench_n1_fern.json"):
+            assert "frame_ms_c_abi" not in line and (line["dtype"] == "bf16") == ("bf16" in name) and ("fern" in line["config"]["workload"]) == ("fern" in name)
         else:
             assert "frame_ms_c_abi" not in line and line["frame_checksum"] == 3074984520147328127
             st = line["staging"]
