@@ -53,7 +53,8 @@ int pack_map_bf16(const mi_nerf_net*, int32_t*, size_t);
 int pack_apply_bf16(const mi_nerf_net*, const int32_t*, const float*, void*, size_t, hipStream_t);
 int mlp_rays_fp32(const mi_nerf_net*, const void*, const float*, const float*, int64_t, int, float*, hipStream_t);
 int mlp_embedded_fp32(const mi_nerf_net*, const void*, const float*, int64_t, float*, hipStream_t);
-int mlp_rays_bf16(const mi_nerf_net*, const void*, const float*, const float*, int64_t, int, float*, hipStream_t, int points_per_wave, const StratDraw* strat);
+int mlp_rays_bf16(const mi_nerf_net*, const void*, const float*, const float*, int64_t, int, float*, hipStream_t, int points_per_wave, const StratDraw* strat,
+                  FineDraw* fine = nullptr);
 size_t packed_bytes_f16s(const mi_nerf_net*);
 int pack_f16s(const mi_nerf_net*, const mi_nerf_params*, void*, size_t);
 int mlp_rays_f16s(const mi_nerf_net*, const void*, const float*, const float*, int64_t, int, float*, hipStream_t);
@@ -434,11 +435,17 @@ int mi_nerf_render_rays(const mi_nerf_net* net, const void* packed_c, const void
     const bool fine_f16s = cfg->mode == MI_NERF_MODE_F16S;
     const bool coarse_bf16 = mode_is_bf16(cfg->mode);
     const bool fine_bf16 = mode_is_bf16(cfg->mode) || cfg->mode == MI_NERF_MODE_F16S_BF16;
+    FineDraw fd{};
     if (coarse_bf16) {
         // the bf16 kernel draws the stratified depths in its own prologue and writes z_c (one launch fewer: at a 512-ray shard a
         // launch is ~4 us of a ~130 us step)
+        // ... and, for a small shard (one 32-point unit per wave: <= 512 rays on 256 CUs), render_rays' middle as well: `fd.taken`
         const StratDraw sd{cfg->near_, cfg->far_, t_rand, cfg->seed, cfg->ray_offset, z_c};
-        if (int rc = mlp_rays_bf16(net, packed_c, rays, nullptr, n, Sc, raw_c, st, ppw, &sd)) return rc;
+        if (cfg->Nf > 0) {
+            MN_CHECK_ARG(packed_f && rgb_f && disp_f, "fine pass needs packed_fine and outputs");
+            fd = FineDraw{cfg->Nf, cfg->det, u, cfg->seed, cfg->ray_offset, rgb_c, disp_c, wts_c, (float*)(w + L.z_f), false};
+        }
+        if (int rc = mlp_rays_bf16(net, packed_c, rays, nullptr, n, Sc, raw_c, st, ppw, &sd, cfg->Nf > 0 && ppw == 0 ? &fd : nullptr)) return rc;
     } else {
         if (int rc = stage_stratified(n, Sc, cfg->near_, cfg->far_, t_rand, cfg->seed, cfg->ray_offset, z_c, st)) return rc;
         if (int rc = coarse_f16s ? mlp_rays_f16s(net, packed_c, rays, z_c, n, Sc, raw_c, st) : mlp_rays_fp32(net, packed_c, rays, z_c, n, Sc, raw_c, st)) return rc;
@@ -448,8 +455,9 @@ int mi_nerf_render_rays(const mi_nerf_net* net, const void* packed_c, const void
         // 3-a) + 1-b) composite, resample + merge in one launch; 2-b) fine net over all Sc+Nf depths; 3-b) composite   (:198-213)
         float* z_f = (float*)(w + L.z_f);
         float* raw_f = (float*)(w + L.raw_f);
-        if (int rc = stage_composite_fine_z(raw_c, z_c, rays, n, Sc, cfg->Nf, cfg->det, u, cfg->seed, cfg->ray_offset, rgb_c, disp_c, wts_c, z_f, st))
-            return rc;
+        if (!fd.taken)        // (a small bf16 coarse launch has done this in its epilogue)
+            if (int rc = stage_composite_fine_z(raw_c, z_c, rays, n, Sc, cfg->Nf, cfg->det, u, cfg->seed, cfg->ray_offset, rgb_c, disp_c, wts_c, z_f, st))
+                return rc;
         if (int rc = fine_f16s ? mlp_rays_f16s(net, packed_f, rays, z_f, n, St, raw_f, st)
                           : fine_bf16 ? mlp_rays_bf16(net, packed_f, rays, z_f, n, St, raw_f, st, ppw, nullptr)
                                       : mlp_rays_fp32(net, packed_f, rays, z_f, n, St, raw_f, st)) return rc;

@@ -88,6 +88,9 @@ __device__ __forceinline__ float jitter_at(const Jitter& j, long long ray, int s
 
 // what a kernel needs to draw the coarse depths itself (host side of mlp_rays_bf16's strat argument)
 struct StratDraw { float near_, far_; const float* t_rand; uint32_t seed; int64_t ray0; float* z_out; };
+// what the bf16 coarse launch needs to ALSO do render_rays' middle (composite the coarse pass, resample, merge: stage_composite_fine_z) for the
+// rays its workgroups wholly own -- offered by mi_nerf_render_rays, taken by mlp_rays_bf16 only for small launches (`taken` says which)
+struct FineDraw { int Nf, det; const float* u; uint32_t seed; int64_t ray0; float *rgb_c, *disp_c, *w_c, *z_f; bool taken; };
 // one stratified coarse depth (nerf_process.py:42-60): sample i of S on ray `ray`
 __device__ __forceinline__ float stratified_depth(long long ray, int i, int S, float step, float near_, float far_, const Jitter& t_rand) {
     const float zi = strat_edge(i, S, step, near_, far_);

@@ -50,6 +50,7 @@
 #include <vector>
 #include "common.h"
 #include "layout.h"
+#include "stage_dev.h"
 
 namespace minerf {
 
@@ -319,6 +320,11 @@ struct MlpArgsB {
     unsigned stream_bytes, side_floats;
     unsigned o_bias_trunk, o_bias_feat, o_bias_d, o_head_b, o_wdir_t;
     unsigned long long* diag;   // MN_DIAG builds only: per-wave cycle sums of the kernel's segments
+    // small coarse launches (one 32-point unit per wave, two units per ray: a workgroup's four waves hold rays 2b and 2b + 1 whole): the
+    // workgroup composites its two rays and draws their fine depths in the kernel's epilogue (stage_dev.h), fz_on != 0
+    int fz_on, fz_Nf, fz_n2, fz_det;
+    Jitter fz_u;
+    float *fz_rgb, *fz_disp, *fz_w, *fz_zf;
 };
 
 #ifdef MN_DIAG
@@ -940,6 +946,25 @@ void mlp_bf16_kernel(const MlpArgsB a) {
 #endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    // ---- small coarse launch: render_rays' middle for the two rays this workgroup owns (nerf_process.py:198-203) -----------------------------
+    // One 32-point unit per wave, flat walk, 64 samples = two units per ray: waves 4b .. 4b + 3 computed rays 2b and 2b + 1 whole.  Their raw
+    // outputs and depths are in global memory (the stores above have completed: vmcnt(0); same CU, same L1: nothing to invalidate at workgroup
+    // scope), the weight ring is quiescent (its last DMAs have landed) and becomes the two waves' scratch.  Waves 0 and 1 each run the SAME
+    // device functions the stage kernel runs (composite_fine_z_kernel, stages.hip): identical results, one launch and ~4 us fewer per step
+    // at the 512-ray shard of an 8-GPU split.  Larger launches leave it to the stage kernel (a wave per ray there, thousands in flight).
+    if constexpr (NPA == 2 && NPB == 0 && NWV == 4) {
+        if (a.fz_on) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            const long long ray = 2ll * blockIdx.x + wave;
+            if (wave < 2 && ray < (long long)a.n_rays) {
+                float* mine = (float*)smem + wave * (a.S + 2 * (a.S - 1) + a.fz_n2);
+                composite_ray<1>(a.out, a.z_out, a.rays, 6, ray, a.S, lane, a.fz_rgb, a.fz_disp, nullptr, a.fz_w, nullptr, mine);
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                fine_z_ray(a.z_out, mine, ray, a.S, a.fz_Nf, a.fz_n2, a.fz_det, a.fz_u, a.fz_zf, nullptr, mine + a.S, lane);
+            }
+        }
+    }
 }
 
 // The walk of one phase: shape NP over the tiles [tile0, tile_end) on a grid of `grid` workgroups.
@@ -1016,7 +1041,8 @@ static int launch_bf16(MlpArgsB a, long long split, long long n_wtiles, hipStrea
 // points_per_wave: 0 = chosen per launch (pick_np), 64 / 32 = forced (A/B measurements, parity tests of each shape)
 // z_dev == NULL (strat != NULL): the kernel draws the stratified depths of render_rays' coarse pass itself and writes them to strat->z_out
 int mlp_rays_bf16(const mi_nerf_net* net, const void* packed_dev, const float* rays_dev, const float* z_dev, int64_t n_rays, int S,
-                  float* raw_dev, hipStream_t st, int points_per_wave, const StratDraw* strat) {
+                  float* raw_dev, hipStream_t st, int points_per_wave, const StratDraw* strat, FineDraw* fine) {
+    if (fine) fine->taken = false;
     if (int rc = check_net_bf16(net)) return rc;
     MN_CHECK_ARG(n_rays >= 0 && S >= 1, "bad sizes n_rays=%lld S=%d", (long long)n_rays, S);
     MN_CHECK_ARG(points_per_wave == 0 || points_per_wave == 32 || points_per_wave == 64 || points_per_wave == 832,
@@ -1057,7 +1083,23 @@ int mlp_rays_bf16(const mi_nerf_net* net, const void* packed_dev, const float* r
     const long long round4 = (long long)device_cus() * 4 * 2, round2 = (long long)device_cus() * 4;
     const long long main_tiles = (n_wtiles / round4) * round4, rem = n_wtiles - main_tiles;
     if (rem == 0 || rem > round2) return launch_bf16<4, 0, 4>(a, n_wtiles, n_wtiles, st);
-    if (main_tiles == 0) return launch_bf16<2, 0, 4>(a, n_wtiles, n_wtiles, st);
+    if (main_tiles == 0) {
+        // one round of 32-point units, one unit per wave.  A coarse pass of 33..64 samples is two units per ray, so a workgroup's four waves hold
+        // two rays whole: it takes render_rays' middle for them too when the caller offers it (`fine`; the kernel's epilogue).  The grid is one
+        // workgroup per four tiles and the walk flat (n_iter == 1: make_phase), which is what the epilogue's ray = 2 * block + wave assumes.
+        if (fine && !z_dev && a.tpr == 2 && fine->Nf >= 1 && S >= 3) {
+            int n2 = 2;
+            while (n2 < S + fine->Nf) n2 <<= 1;
+            const size_t scratch = (size_t)2 * (S + 2 * (S - 1) + n2) * sizeof(float);
+            if (scratch <= (size_t)BRING_BYTES && n2 <= 512) {
+                a.fz_on = 1; a.fz_Nf = fine->Nf; a.fz_n2 = n2; a.fz_det = fine->det;
+                a.fz_u = Jitter{fine->u, fine->seed, 1u, (long long)fine->ray0};
+                a.fz_rgb = fine->rgb_c; a.fz_disp = fine->disp_c; a.fz_w = fine->w_c; a.fz_zf = fine->z_f;
+                fine->taken = true;
+            }
+        }
+        return launch_bf16<2, 0, 4>(a, n_wtiles, n_wtiles, st);
+    }
     return launch_bf16<4, 2, 4>(a, main_tiles, n_wtiles, st);
 }
 

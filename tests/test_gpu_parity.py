@@ -798,6 +798,37 @@ def test_bf16_small_launch_shape_whole_step(packed_big, lego_rays):
     assert torch.equal(NP.render_rays(rays, packed_big, None, opts, t_rand=a["_t_rand"], u=a["_u"], bf16=True)["rgb_f"], outs[0][2])
 
 
+@pytest.mark.parametrize("n,Sc,Nf,det,inject", [(512, 64, 128, False, False), (511, 64, 128, False, True), (1, 64, 128, False, False), (2, 64, 128, True, False),
+                                                (333, 40, 17, False, True), (300, 64, 192, False, False), (512, 33, 64, True, False), (513, 64, 128, False, False),
+                                                (700, 64, 128, False, True), (256, 64, 0, False, False), (100, 32, 32, False, False)])
+def test_bf16_small_coarse_launch_does_the_middle_of_render_rays_itself(n, Sc, Nf, det, inject, packed_big, lego_rays):
+    """Round 6: a small bf16 coarse launch (one 32-point unit per wave: up to 512 rays on 256 CUs, 33..64 coarse samples) composites the two rays each
+    workgroup owns and draws their fine depths in the kernel's epilogue -- the device functions of composite_fine_z_kernel, called in place -- so the
+    step has one launch fewer.  Every output and intermediate equals, bit for bit, the same step with the launch shape pinned (64 or 32 points per
+    wave: the pinned forms never fuse and run the stage kernel): odd ray counts (a workgroup with one ray), one ray, ragged sample counts,
+    deterministic and injected jitter, sizes and shapes that must NOT fuse (513 / 700 rays, 32 coarse samples = one tile per ray, coarse only)."""
+    opts = make_opts(N_samples_c=Sc, N_samples_f=Nf, perturb=0.0 if det else 1.0)
+    rays = lego_rays[:n].contiguous()
+    blobs = packed_big.bf16()
+    t_rand = ops.fill_uniform(5, 0, 7, n, Sc, DEV) if inject else None
+    u = ops.fill_uniform(5, 1, 7, n, Nf, DEV) if (inject and Nf > 0 and not det) else None
+    res = {}
+    for ppw in (0, 32, 64):
+        cfg = ops.render_cfg(opts.near, opts.far, Sc, Nf, det, True, points_per_wave=ppw, seed=5, ray_offset=7)
+        ws = torch.full((ops.workspace_layout(cfg, n).total,), 0xFF, dtype=torch.uint8, device=DEV)      # NaN bit patterns: an unwritten slot shows
+        out = ops.render_rays(packed_big.net, blobs[0], blobs[1] if Nf > 0 else None, cfg, rays, t_rand, u, workspace=ws)
+        res[ppw] = (out[:4], {k: v.clone() for k, v in ops.workspace_views(cfg, n, out[4]).items()})
+    for ppw in (32, 64):
+        for x, y in zip(res[0][0], res[ppw][0]):
+            assert (x is None and y is None) or torch.equal(x, y), (ppw, n, Sc, Nf)
+        for k in res[0][1]:
+            assert torch.equal(res[0][1][k], res[ppw][1][k]), (k, ppw, n, Sc, Nf)
+    assert all(torch.isfinite(v).all() for v in res[0][1].values())
+    if Nf > 0:
+        z_f = res[0][1]["z_f"]
+        assert bool((z_f[:, 1:] >= z_f[:, :-1]).all()) and torch.isfinite(res[0][0][2]).all()
+
+
 @pytest.mark.parametrize("D,skip", [(7, 5), (3, -1), (8, 3), (2, -1), (6, 4), (9, 0)])
 def test_bf16_other_depths_and_skip_positions(D, skip, lego_rays):
     """The bf16 kernel addresses its B fragments by explicit AGPR number, with two statically unrolled polarities (which fragment
