@@ -33,6 +33,11 @@
 //     kernel keeps one full-precision evaluation per channel; this is the bf16 variant's own accuracy contract
 //     (checked against an oracle with the same rounding points, and as PSNR against the fp32 path).
 //
+//   * SMALL COARSE LAUNCHES DO render_rays' MIDDLE THEMSELVES (round 6).  One 32-point unit per wave and 33..64 coarse samples = two units per
+//     ray: a workgroup's four waves hold two rays whole, so its epilogue composites them and draws their fine depths (composite_ray +
+//     fine_z_ray of stage_dev.h -- the stage kernel's own device functions: bit-identical) and mi_nerf_render_rays skips that launch:
+//     -2.2 us of a ~125 us step at the 512-ray shard of an 8-GPU split (profiles/r06_bf16_fused_stages_ab.txt).
+//
 //   A fragment: lane l (i = l&15, q = l>>4) holds A[i][k = 8q + j], j = 0..7  (8 bf16 = 16 B = one ds_read_b128)
 //   B fragment: lane l holds B[k = 8q + j][col = l&15]
 //   D (4 registers): col = l&15, row = 4q + r
