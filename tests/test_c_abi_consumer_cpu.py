@@ -29,3 +29,14 @@ def test_header_compiles_as_c99_and_the_library_links_and_answers(tmp_path, std)
     run = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert run.returncode == 0, run.stdout + run.stderr
     assert "c_abi consumer ok: ABI 4" in run.stdout
+
+
+def test_every_entry_point_is_mapped_to_the_reference_in_integration_md():
+    """INTEGRATION.md section 3 maps each C entry point to the reference code it replaces (or says that it replaces nothing): every function the
+    header declares appears there by name."""
+    import re
+    with open(os.path.join(ROOT, "include", "mi_nerf.h")) as f:
+        names = sorted(set(re.findall(r"\b(mi_nerf_[a-z0-9_]+)\s*\(", f.read())))
+    with open(os.path.join(ROOT, "INTEGRATION.md")) as f:
+        doc = f.read()
+    assert len(names) == 68 and [n for n in names if n not in doc] == []
