@@ -208,8 +208,8 @@ int mi_nerf_composite(const float* raw_dev, const float* z_dev, const float* ray
  * t_rand [n,Sc] / u [n,Nf] to inject explicit uniforms, or NULL to have the consuming kernels draw them from the counter-based
  * generator keyed on (cfg->seed, cfg->ray_offset + ray index, sample index) -- exactly the values mi_nerf_fill_uniform(seed,
  * stream 0 / 1, ray_offset, ...) writes, without the tensors.  u is ignored when det != 0.
- * Launches: stratified depths (bf16: drawn in the coarse net kernel) | coarse net | composite + resample + merge (bf16, at most two rays
- * per CU and 33..64 coarse samples: done in the coarse net kernel's epilogue by the workgroup that owns the rays) | fine net | composite.
+ * Launches: stratified depths (bf16: drawn in the coarse net kernel) | coarse net | composite + resample + merge (bf16, at most four rays
+ * per CU and 33..64 coarse samples: done in the coarse net kernel's epilogue by the waves that own the rays) | fine net | composite.
  * Workspace (caller-allocated, mi_nerf_render_workspace_bytes): z_c, raw_c, weights_c, z_f, raw_f.
  * Outputs: rgb_c [n,3], disp_c [n]; rgb_f [n,3], disp_f [n] when Nf > 0 (else may be NULL). */
 typedef struct mi_nerf_render_cfg {

@@ -36,7 +36,8 @@
 //   * SMALL COARSE LAUNCHES DO render_rays' MIDDLE THEMSELVES (round 6).  One 32-point unit per wave and 33..64 coarse samples = two units per
 //     ray: a workgroup's four waves hold two rays whole, so its epilogue composites them and draws their fine depths (composite_ray +
 //     fine_z_ray of stage_dev.h -- the stage kernel's own device functions: bit-identical) and mi_nerf_render_rays skips that launch:
-//     -2.2 us of a ~125 us step at the 512-ray shard of an 8-GPU split (profiles/r06_bf16_fused_stages_ab.txt).
+//     -2.2 us of a ~125 us step at the 512-ray shard of an 8-GPU split (profiles/r06_bf16_fused_stages_ab.txt).  From 513 to 1024 rays a wave's
+//     one 64-point unit IS a ray, and every wave does the middle for its own ray (-1.8 us of ~205 at 1024 rays).
 //
 //   A fragment: lane l (i = l&15, q = l>>4) holds A[i][k = 8q + j], j = 0..7  (8 bf16 = 16 B = one ds_read_b128)
 //   B fragment: lane l holds B[k = 8q + j][col = l&15]
@@ -970,6 +971,21 @@ void mlp_bf16_kernel(const MlpArgsB a) {
             }
         }
     }
+    // The same one step up in size (513..1024 rays on 256 CUs): one 64-point unit per wave and 33..64 coarse samples = one unit per RAY, so every wave
+    // owns the ray it computed and does the middle for it (all four waves busy; each its own slice of the quiescent ring).
+    if constexpr (NPA == 4 && NPB == 0 && NWV == 4) {
+        if (a.fz_on) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            const long long ray = 4ll * blockIdx.x + wave;
+            if (ray < (long long)a.n_rays) {
+                float* mine = (float*)smem + wave * (a.S + 2 * (a.S - 1) + a.fz_n2);
+                composite_ray<1>(a.out, a.z_out, a.rays, 6, ray, a.S, lane, a.fz_rgb, a.fz_disp, nullptr, a.fz_w, nullptr, mine);
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                fine_z_ray(a.z_out, mine, ray, a.S, a.fz_Nf, a.fz_n2, a.fz_det, a.fz_u, a.fz_zf, nullptr, mine + a.S, lane);
+            }
+        }
+    }
 }
 
 // The walk of one phase: shape NP over the tiles [tile0, tile_end) on a grid of `grid` workgroups.
@@ -1086,23 +1102,30 @@ int mlp_rays_bf16(const mi_nerf_net* net, const void* packed_dev, const float* r
     // A 512-ray shard of BASELINE config #5 (8 GPUs): coarse 1024 tiles = one 32-point round (was half the chip for a full pass);
     // fine 3072 tiles = one 64-point round + one 32-point round (was two full passes, the second half empty).
     const long long round4 = (long long)device_cus() * 4 * 2, round2 = (long long)device_cus() * 4;
+    // render_rays' middle in the coarse launch's epilogue (`fine` offered; a coarse pass of 33..64 samples; one unit per wave, flat walk -- which is what
+    // the epilogue's ray numbering assumes): `slices` waves of a workgroup each take a ray and a slice of the ring as scratch
+    auto take_middle = [&](int slices) {
+        if (!(fine && !z_dev && a.tpr == 2 && fine->Nf >= 1 && S >= 3)) return;
+        int n2 = 2;
+        while (n2 < S + fine->Nf) n2 <<= 1;
+        const size_t scratch = (size_t)slices * (S + 2 * (S - 1) + n2) * sizeof(float);
+        if (scratch > (size_t)BRING_BYTES || n2 > 512) return;
+        a.fz_on = 1; a.fz_Nf = fine->Nf; a.fz_n2 = n2; a.fz_det = fine->det;
+        a.fz_u = Jitter{fine->u, fine->seed, 1u, (long long)fine->ray0};
+        a.fz_rgb = fine->rgb_c; a.fz_disp = fine->disp_c; a.fz_w = fine->w_c; a.fz_zf = fine->z_f;
+        fine->taken = true;
+    };
     const long long main_tiles = (n_wtiles / round4) * round4, rem = n_wtiles - main_tiles;
-    if (rem == 0 || rem > round2) return launch_bf16<4, 0, 4>(a, n_wtiles, n_wtiles, st);
+    if (rem == 0 || rem > round2) {
+        // at most one 64-point unit per wave and one unit per ray (33..64 samples): every wave owns the ray it computes (513..1024 rays on 256 CUs)
+        if (n_wtiles <= round4) take_middle(4);
+        return launch_bf16<4, 0, 4>(a, n_wtiles, n_wtiles, st);
+    }
     if (main_tiles == 0) {
         // one round of 32-point units, one unit per wave.  A coarse pass of 33..64 samples is two units per ray, so a workgroup's four waves hold
         // two rays whole: it takes render_rays' middle for them too when the caller offers it (`fine`; the kernel's epilogue).  The grid is one
         // workgroup per four tiles and the walk flat (n_iter == 1: make_phase), which is what the epilogue's ray = 2 * block + wave assumes.
-        if (fine && !z_dev && a.tpr == 2 && fine->Nf >= 1 && S >= 3) {
-            int n2 = 2;
-            while (n2 < S + fine->Nf) n2 <<= 1;
-            const size_t scratch = (size_t)2 * (S + 2 * (S - 1) + n2) * sizeof(float);
-            if (scratch <= (size_t)BRING_BYTES && n2 <= 512) {
-                a.fz_on = 1; a.fz_Nf = fine->Nf; a.fz_n2 = n2; a.fz_det = fine->det;
-                a.fz_u = Jitter{fine->u, fine->seed, 1u, (long long)fine->ray0};
-                a.fz_rgb = fine->rgb_c; a.fz_disp = fine->disp_c; a.fz_w = fine->w_c; a.fz_zf = fine->z_f;
-                fine->taken = true;
-            }
-        }
+        take_middle(2);
         return launch_bf16<2, 0, 4>(a, n_wtiles, n_wtiles, st);
     }
     return launch_bf16<4, 2, 4>(a, main_tiles, n_wtiles, st);

@@ -802,14 +802,16 @@ def test_bf16_small_launch_shape_whole_step(packed_big, lego_rays):
                                                 (333, 40, 17, False, True), (300, 64, 192, False, False), (512, 33, 64, True, False), (513, 64, 128, False, False),
                                                 (700, 64, 128, False, True), (256, 64, 0, False, False), (100, 32, 32, False, False),
                                                 (342, 64, 128, False, False), (343, 64, 128, False, True), (400, 64, 100, True, False), (450, 64, 97, False, False),
-                                                (341, 64, 128, False, False), (512, 64, 130, False, False)])
+                                                (341, 64, 128, False, False), (512, 64, 130, False, False), (1024, 64, 128, False, False), (1023, 64, 128, False, True),
+                                                (1025, 64, 128, False, False), (1000, 48, 64, True, False)])
 def test_bf16_small_coarse_launch_does_the_middle_of_render_rays_itself(n, Sc, Nf, det, inject, packed_big, lego_rays):
     """Round 6: a small bf16 coarse launch (one 32-point unit per wave: up to 512 rays on 256 CUs, 33..64 coarse samples) composites the two rays each
     workgroup owns and draws their fine depths in the kernel's epilogue -- the device functions of composite_fine_z_kernel, called in place -- so the
-    step has one launch fewer.  (The same for the LAST compositing -- the fine launch dealing its tiles so that a workgroup owns two rays -- was built
+    step has one launch fewer; from 513 to 1024 rays (one 64-point unit per wave = one unit per ray) every wave does that for the ray it computed.  (The same for the LAST compositing -- the fine launch dealing its tiles so that a workgroup owns two rays -- was built
     and measured in round 6 and is not shipped: +1 us at 512 rays, profiles/r06_bf16_fused_stages_ab.txt.)  Every output and intermediate equals, bit for bit, the same step with the launch shape pinned (64 or 32 points per
     wave: the pinned forms never fuse and run the stage kernel): odd ray counts (a workgroup with one ray), one ray, ragged sample counts,
-    deterministic and injected jitter, sizes and shapes that must NOT fuse (513 / 700 rays, 32 coarse samples = one tile per ray, coarse only)."""
+    deterministic and injected jitter, both ownership forms (<= 512 rays: two rays per workgroup; 513..1024: a ray per wave), sizes and shapes that must NOT
+    fuse (1025 rays, 32 coarse samples = one tile per ray, coarse only)."""
     opts = make_opts(N_samples_c=Sc, N_samples_f=Nf, perturb=0.0 if det else 1.0)
     rays = lego_rays[:n].contiguous()
     blobs = packed_big.bf16()
