@@ -8,7 +8,7 @@ dev=torch.device('cuda:0')
 sd=synthetic.make_state_dict(0,8,256); packed=weights.PackedNeRF.from_state_dict(sd,dev)
 K,H,W=synthetic.lego_camera(); pose=synthetic.pose_spherical(0.,-30.,4.)
 blobs=packed.bf16()
-for n in (512,700,1024,2048,4096):
+for n in (256,512,1024,4096):
     pix=torch.from_numpy(synthetic.pixel_batch(H,W,n,0)).to(dev)
     o,d=ops.make_o_d_pixels(W,H,K,pose,pix); rays=torch.cat([o,d],-1).contiguous()
     res={}
