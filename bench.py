@@ -583,8 +583,10 @@ def worker(args) -> None:
         torch.cuda.synchronize(dev)
         peaked = {"network": "Xavier(seed 0) 8x256 with the density head x200 (bench default: x20): hard surfaces, a spiked coarse pdf",
                   "bf16": quality(b16_pk, ref_pk), "coarse_f16s_fine_bf16": quality(mix_pk, ref_pk),
-                  "trained_networks": "profiles/r05_trained_weights.txt: bf16 47.8-49.5 dB vs the fp32 frame, max |d rgb| 0.145-0.147 (37 grey levels) on the build's own "
-                                      "trained scenes; tests/test_gpu_trained.py::test_trained_reduced_precision_frames prints both variants per scene"}
+                  "trained_networks": "profiles/r06_trained_weights_long.txt (20 000-step networks): all-bf16 51.4 / 47.7 dB vs the fp32 frame, max |d rgb| 0.35 / 0.14, "
+                                      "and -0.117 dB against ground truth on the 33 dB hard-surface scene (outside the north star's 0.05 dB); coarse_f16s_fine_bf16 "
+                                      "67.2 / 62.7 dB, max |d rgb| 0.02, -0.004 dB.  tests/test_gpu_trained.py::test_trained_reduced_precision_frames prints both per scene "
+                                      "(profiles/r06_trained_weights.txt: the suite's 3000-step networks)"}
         del packed_pk, pk16, ref_pk, b16_pk, mix_pk
 
         bf16_leg = {"what": "BASELINE config #5: the same step with bf16 weights / activations on v_mfma_f32_16x16x32_bf16 (fp32 accumulate), this run's shard and jitter. "
